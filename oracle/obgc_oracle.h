@@ -1,0 +1,208 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded, re-entrant CPU restatement of the reference's column
+ * hot path (E3SM-Project/Ocean-BGC: BGC_mod.F90, co2calc.F90, DMS_mod.F90,
+ * MACROS_mod.F90).  It exists so that tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py can check / time against the reference's
+ * arithmetic on machines where /root/reference does not exist.  Nothing under
+ * ocean-bgc_amd/ includes, links or loads this.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py compares every
+ * output of every routine here against oracle/_ref/libbgc_ref.so (the unmodified
+ * reference compiled with amdflang -O2) and against the committed fixtures in
+ * tests/golden/ generated from that library (tests/golden/make_golden.py).
+ *
+ * Array layout = the reference's: Fortran X(k, column[, n]) i.e. k fastest, then
+ * column, then tracer / autotroph;  (column, n) for surface flux arrays.
+ * Indices stored in the parameter structs are 1-based like the reference's.
+ */
+#ifndef OBGC_ORACLE_H
+#define OBGC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORA_AUTOTROPH_CNT 4
+#define ORA_BGC_NTRACER 30
+#define ORA_DMS_NTRACER 14
+#define ORA_MACROS_NTRACER 8
+
+/* autotroph_type, BGC_parms.F90:51-79 (names dropped: not arithmetic) */
+typedef struct {
+  int Nfixer, imp_calcifier, exp_calcifier, grazee_ind, temp_function;
+  int Chl_ind, C_ind, Fe_ind, Si_ind, CaCO3_ind;
+  double kFe, kPO4, kDOP, kNO3, kNH4, kSiO3, Qp, gQfe_0, gQfe_min, alphaPI, PCref,
+      thetaN_max, loss_thres, loss_thres2, temp_thres, temp_thresS, temp_thresN,
+      temp_optN, temp_optS, mort, mort2, agg_rate_max, agg_rate_min, z_umax_0,
+      z_grz, graze_zoo, graze_poc, graze_doc, loss_poc, f_zoo_detr;
+} ora_autotroph;
+
+/* tracer-index order = BGC_indices_type declaration order, BGC_parms.F90:81-112 */
+enum {
+  ORA_po4, ORA_no3, ORA_sio3, ORA_nh4, ORA_fe, ORA_o2, ORA_dic, ORA_dic_alt_co2,
+  ORA_alk, ORA_doc, ORA_don, ORA_dofe, ORA_dop, ORA_dopr, ORA_donr, ORA_zooC,
+  ORA_spC, ORA_spChl, ORA_spFe, ORA_spCaCO3, ORA_diatC, ORA_diatChl, ORA_diatFe,
+  ORA_diatSi, ORA_phaeoC, ORA_phaeoChl, ORA_phaeoFe, ORA_diazC, ORA_diazChl,
+  ORA_diazFe
+};
+
+typedef struct {
+  ora_autotroph autotrophs[ORA_AUTOTROPH_CNT];
+  int ind[ORA_BGC_NTRACER];                /* 1-based tracer slots */
+  int sp_ind, diat_ind, diaz_ind, phaeo_ind; /* 1-based autotroph slots */
+  /* BGC_parms.F90:346-365 */
+  double parm_Fe_bioavail, parm_o2_min, parm_o2_min_delta, parm_kappa_nitrif,
+      parm_nitrif_par_lim, parm_z_mort_0, parm_z_mort2_0, parm_labile_ratio,
+      parm_POMbury, parm_BSIbury, parm_fe_scavenge_rate0, parm_f_prod_sp_CaCO3,
+      parm_POC_diss, parm_SiO2_diss, parm_CaCO3_diss;
+  double parm_scalelen_z[4], parm_scalelen_vals[4];
+  double T0_Kelvin_BGC;                    /* BGC_parms.F90:45, host-set */
+  int lrest_po4, lrest_no3, lrest_sio3;    /* BGC_mod.F90:131-134, never set there */
+} ora_bgc_params;
+
+/* DMS_parms.F90:160-192 and indices 62-77 */
+typedef struct {
+  int ind[ORA_DMS_NTRACER]; /* dms dmsp no3 doc zooC spC spCaCO3 diatC diazC phaeoC spChl diatChl diazChl phaeoChl */
+  double k_S_p_base, zooC_avg, mort, k_conv, k_S_z, B_preexp, B_exp, k_S_B, k_bkgnd,
+      j_dms_perI, inject_scale, T_cryo_hi, T_cryo_lo, T_lo, T_hi, Min_cyano_frac,
+      Max_cyano_frac, Min_yld, Max_yld, G_phaeo_S, Sp_ref, Stress_mult, R,
+      Rs2n_diat, Rs2n_phaeo, Rs2n_cocco, Rs2n_cyano, Rs2n_eukar, Rs2n_diaz,
+      f_qsw_par_DMS;
+} ora_dms_params;
+
+/* MACROS_parms.F90:122-132 and indices 62-71 */
+typedef struct {
+  int ind[ORA_MACROS_NTRACER]; /* prot poly lip zooC spC diatC diazC phaeoC */
+  double f_prot, f_poly, f_lip, k_C_p_base, zooC_avg, mort, k_prot_bac, k_poly_bac,
+      k_lip_bac, inject_scale;
+} ora_macros_params;
+
+/* diagnostic slot numbers; same order as oracle/fields.py */
+#define ORA_DIAG_KC_LIST(X) \
+  X(tot_Nfix) X(O2_PRODUCTION) X(O2_CONSUMPTION) X(AOU) X(PO4_RESTORE) X(NO3_RESTORE) \
+  X(SiO3_RESTORE) X(PAR_avg) X(POC_FLUX_IN) X(POC_PROD) X(POC_REMIN) X(POC_ACCUM) \
+  X(CaCO3_FLUX_IN) X(CaCO3_PROD) X(CaCO3_REMIN) X(SiO2_FLUX_IN) X(SiO2_PROD) \
+  X(SiO2_REMIN) X(dust_FLUX_IN) X(dust_REMIN) X(P_iron_FLUX_IN) X(P_iron_PROD) \
+  X(P_iron_REMIN) X(auto_graze_TOT) X(zoo_loss) X(photoC_TOT) X(photoC_NO3_TOT) \
+  X(DOC_prod) X(DOC_remin) X(DON_prod) X(DON_remin) X(DOFe_prod) X(DOFe_remin) \
+  X(DOP_prod) X(DOP_remin) X(Fe_scavenge) X(Fe_scavenge_rate) X(NITRIF) X(DENITRIF) \
+  X(DONr_remin) X(DOPr_remin) X(CO3) X(HCO3) X(H2CO3) X(pH_3D) X(CO3_ALT_CO2) \
+  X(HCO3_ALT_CO2) X(H2CO3_ALT_CO2) X(pH_3D_ALT_CO2) X(co3_sat_calc) X(co3_sat_arag) \
+  X(calcToSed) X(pocToSed) X(ponToSed) X(popToSed) X(bsiToSed) X(dustToSed) \
+  X(pfeToSed) X(SedDenitrif) X(OtherRemin) X(tot_CaCO3_form)
+#define ORA_DIAG_KCA_LIST(X) \
+  X(N_lim) X(P_lim) X(Fe_lim) X(SiO3_lim) X(light_lim) X(photoC) X(photoC_NO3) \
+  X(photoFe) X(photoNO3) X(photoNH4) X(DOP_uptake) X(PO4_uptake) X(auto_graze) \
+  X(auto_loss) X(auto_agg) X(bSi_form) X(CaCO3_form) X(Nfix)
+#define ORA_DIAG_CA_LIST(X) X(photoC_zint) X(photoC_NO3_zint) X(CaCO3_form_zint)
+#define ORA_DIAG_C_LIST(X) \
+  X(photoC_TOT_zint) X(photoC_NO3_TOT_zint) X(Jint_Ctot) X(Jint_100m_Ctot) X(Jint_Ntot) \
+  X(Jint_100m_Ntot) X(Jint_Ptot) X(Jint_100m_Ptot) X(Jint_Sitot) X(Jint_100m_Sitot) \
+  X(Chl_TOT_zint_100m) X(tot_CaCO3_form_zint) X(tot_bSi_form) X(zsatcalc) X(zsatarag) \
+  X(O2_ZMIN) X(O2_ZMIN_DEPTH)
+#define ORA_FLUX_DIAG_LIST(X) \
+  X(pistonVel_O2) X(SCHMIDT_O2) X(O2SAT) X(xkw) X(co2star) X(dco2star) X(pco2surf) \
+  X(dpco2) X(pistonVel_CO2) X(SCHMIDT_CO2) X(co2star_alt_co2) X(dco2star_alt_co2) \
+  X(pco2surf_alt_co2) X(dpco2_alt_co2)
+#define ORA_SURF_FORCING_LIST(X) \
+  X(surfacePressure) X(iceFraction) X(windSpeedSquared10m) X(atmCO2) X(atmCO2_ALT_CO2) \
+  X(surface_pH) X(surface_pH_alt_co2) X(surfaceDepth) X(SST) X(SSS)
+#define ORA_DMS_DIAG_KC_LIST(X) \
+  X(DMS_S_DMSP) X(DMS_S_TOTAL) X(DMS_R_B) X(DMS_R_PHOT) X(DMS_R_BKGND) X(DMS_R_TOTAL) \
+  X(DMSP_S_PHAEO) X(DMSP_S_NONPHAEO) X(DMSP_S_ZOO) X(DMSP_S_TOTAL) X(DMSP_R_B) \
+  X(DMSP_R_BKGND) X(DMSP_R_TOTAL) X(Cyano_frac) X(Cocco_frac) X(Eukar_frac) X(diatS) \
+  X(diatN) X(phytoN) X(coccoS) X(cyanoS) X(eukarS) X(diazS) X(phaeoS) X(zooS) X(zooCC) \
+  X(RSNzoo)
+#define ORA_DMS_FLUX_DIAG_LIST(X) \
+  X(DMS_IFRAC) X(DMS_XKW) X(DMS_ATM_PRESS) X(DMS_PV) X(DMS_SCHMIDT) X(DMS_SAT) \
+  X(DMS_SURF) X(DMS_WS)
+#define ORA_DMS_SURF_FORCING_LIST(X) \
+  X(surfacePressure) X(iceFraction) X(windSpeedSquared10m) X(SST) X(SSS)
+#define ORA_MACROS_DIAG_KC_LIST(X) \
+  X(PROT_S_TOTAL) X(POLY_S_TOTAL) X(LIP_S_TOTAL) X(PROT_R_TOTAL) X(POLY_R_TOTAL) X(LIP_R_TOTAL)
+
+#define ORA_E(pfx, n) pfx##n,
+#define X(n) ORA_E(DKC_, n)
+enum { ORA_DIAG_KC_LIST(X) ORA_NDIAG_KC };
+#undef X
+#define X(n) ORA_E(DKCA_, n)
+enum { ORA_DIAG_KCA_LIST(X) ORA_NDIAG_KCA };
+#undef X
+#define X(n) ORA_E(DCA_, n)
+enum { ORA_DIAG_CA_LIST(X) ORA_NDIAG_CA };
+#undef X
+#define X(n) ORA_E(DC_, n)
+enum { ORA_DIAG_C_LIST(X) ORA_NDIAG_C };
+#undef X
+#define X(n) ORA_E(FD_, n)
+enum { ORA_FLUX_DIAG_LIST(X) ORA_NFLUX_DIAG };
+#undef X
+#define X(n) ORA_E(SF_, n)
+enum { ORA_SURF_FORCING_LIST(X) ORA_NSURF_FORCING };
+#undef X
+#define X(n) ORA_E(DDKC_, n)
+enum { ORA_DMS_DIAG_KC_LIST(X) ORA_NDMS_DIAG_KC };
+#undef X
+#define X(n) ORA_E(DFD_, n)
+enum { ORA_DMS_FLUX_DIAG_LIST(X) ORA_NDMS_FLUX_DIAG };
+#undef X
+#define X(n) ORA_E(DSF_, n)
+enum { ORA_DMS_SURF_FORCING_LIST(X) ORA_NDMS_SURF_FORCING };
+#undef X
+#define X(n) ORA_E(MDKC_, n)
+enum { ORA_MACROS_DIAG_KC_LIST(X) ORA_NMACROS_DIAG_KC };
+#undef X
+
+/* BGC_parms_init (BGC_parms.F90:497-699) + BGC_init's index derivation (BGC_mod.F90:271-321).
+ * `ind` = 30 one-based tracer slots in the ORA_* order above. */
+void ora_bgc_params_init(ora_bgc_params *p, const int *ind, double T0_Kelvin_BGC);
+void ora_bgc_derive_autotroph_indices(ora_bgc_params *p);
+void ora_dms_params_init(ora_dms_params *p, const int *ind);       /* DMS_parms.F90:203-241 */
+void ora_macros_params_init(ora_macros_params *p, const int *ind); /* MACROS_parms.F90:143-162 */
+int ora_sizeof_bgc_params(void);
+int ora_sizeof_dms_params(void);
+int ora_sizeof_macros_params(void);
+
+/* co2calc.F90 public routines, vectorised over n points */
+void ora_comp_co3terms(int n, const int *k, const double *depth, const double *temp, const double *salt,
+                       const double *dic, const double *ta, const double *pt, const double *sit,
+                       const double *phlo, const double *phhi, double *ph, double *h2co3, double *hco3,
+                       double *co3);
+void ora_comp_co3_sat_vals(int n, const int *k, const double *depth, const double *temp,
+                           const double *salt, double *calc, double *arag);
+void ora_co2calc_1point(int n, const double *depth, const double *temp, const double *salt,
+                        const double *dic, const double *ta, const double *pt, const double *sit,
+                        const double *phlo, const double *phhi, const double *xco2, const double *atmpres,
+                        double *ph, double *co2star, double *dco2star, double *pco2surf, double *dpco2);
+/* number of talk_row evaluations of the last ora_comp_co3terms call (instrumentation) */
+long long ora_talk_row_calls(void);
+
+/* BGC_SourceSink, BGC_mod.F90:340-1998.  dkc[61][nc][nz], dkca[18][4][nc][nz],
+ * dca[3][4][nc], dc[17][nc]; any of the four may be NULL (diagnostics skipped). */
+void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *tracers,
+                         const double *temp, const double *salt, const double *zmid, const double *dz,
+                         const double *zbot, const double *lat, const int *kmax, const double *fesed,
+                         const double *dust, const double *sw, double *tend, double *ph_prev,
+                         double *ph_prev_alt, double *dkc, double *dkca, double *dca, double *dc,
+                         int alt_co2_use_eco);
+
+/* BGC_SurfaceFluxes, BGC_mod.F90:2706-2957. forcing[10][nc] (inout), flux arrays [30][nc] */
+void ora_bgc_surface_fluxes(const ora_bgc_params *p, int nz, int nc, const double *tracers,
+                            double *forcing, double *depo, double *river, double *gas, double *seaice,
+                            double *net, double *fdiag, int lcalc_o2, int lcalc_co2);
+
+/* DMS_SourceSink DMS_mod.F90:156-770, DMS_SurfaceFluxes 778-908 */
+void ora_dms_source_sink(const ora_dms_params *p, int nz, int nc, const double *tracers, const double *dz,
+                         const int *kmax, const double *sst, const double *sw, double *tend, double *dkc);
+void ora_dms_surface_fluxes(const ora_dms_params *p, int nz, int nc, const double *tracers,
+                            double *forcing, double *net, double *fdiag, int lcalc);
+
+/* MACROS_SourceSink MACROS_mod.F90:137-411 */
+void ora_macros_source_sink(const ora_macros_params *p, int nz, int nc, const double *tracers,
+                            const int *kmax, double *tend, double *dkc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/libbgc_ref.so,
+built by `make -C oracle ref` from /root/reference with amdflang -O2 -ffp-contract=off).
+
+Run in the build container only (the reference cannot travel):
+    python tests/golden/make_golden.py
+
+Fixtures are DATA: seeded synthetic inputs (ocean-bgc_amd/synth.py) for a handful of
+branch-coverage columns and every output array the reference produced for them.
+
+  config1_1x60.npz       BASELINE config #1: 1 column x 60 levels, every module
+  branch_cols_60.npz     24 columns x 60 levels chosen to hit the branches of SURVEY 8d
+  branch_cols_100.npz    8 columns x 100 levels (crosses 3300 m lysocline test, BGC_mod.F90:2564)
+  kat.npz                known-answer values: O2SAT(10 C, 35 psu) (BGC_mod.F90:3028-3029),
+                         Schmidt numbers, carbonate terms on a small (T,S,depth) grid
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_pkg  # noqa: E402
+
+load_pkg()
+from ocean_bgc_amd import synth  # noqa: E402
+from oracle import refbind  # noqa: E402
+
+
+def pick_columns(nz, want):
+    """Scan generated columns and keep the first hit of each branch predicate."""
+    n = 6000
+    syn = synth.generate(n, nz)
+    t = syn["tracers"]
+    km = syn["kmax"]
+    preds = [
+        ("land", km == 0), ("kmax1", km == 1),
+        ("o2_lt5", (t["o2"][:, 0] < 5) & (km > 1)), ("o2_5_40", (t["o2"][:, 0] >= 5) & (t["o2"][:, 0] < 40) & (km > 1)),
+        ("no3_zero", (t["no3"][:, 0] == 0) & (km > 1)), ("dark", (syn["sw"] < 2.0) & (km > 1)),
+        ("dust_zero", (syn["dust"] == 0) & (km > 1)), ("alk_low", (t["alk"][:, 0] < 2000) & (km > 1)),
+        ("south_warm", (syn["lat"] < 0) & (syn["temp"][:, 0] > 12) & (km > 1)),
+        ("north_warm", (syn["lat"] > 0) & (syn["temp"][:, 0] > 18) & (km > 1)),
+        ("cold", (syn["temp"][:, 0] < 3.0) & (km > 1)), ("bloom", (t["spC"][:, 0] > 4.0) & (km > 1)),
+        ("qcaco3_cap", (t["spCaCO3"][:, 0] > 0.4 * t["spC"][:, 0]) & (km > 1)),
+        ("fe_high", (t["fe"][:, -1] > 0.8e-3) & (km == nz)), ("fe_low", (t["fe"][:, 0] < 1.5e-4) & (km > 1)),
+        ("zero_mask", ((t["spChl"] == 0) | (t["diatChl"] == 0)).any(axis=1) & (km > 1)),
+        ("neg_tracer", (t["nh4"] < 0).any(axis=1) & (km > 1)), ("fe_zero", (t["fe"] == 0).any(axis=1) & (km > 1)),
+    ]
+    cols = []
+    for _, m in preds:
+        idx = np.nonzero(m)[0]
+        for i in idx:
+            if i not in cols:
+                cols.append(int(i))
+                break
+    i = 0
+    while len(cols) < want:
+        if i not in cols:
+            cols.append(i)
+        i += 1
+    return sorted(cols[:want]) if len(cols) > want else sorted(cols)
+
+
+def gather(nz, cols):
+    """Synthetic inputs for an explicit list of global column ids."""
+    parts = [synth.generate(1, nz, col0=c) for c in cols]
+
+    def cat(get):
+        return np.concatenate([get(p) for p in parts], axis=0)
+
+    syn = {k: cat(lambda p, k=k: p[k]) for k in ("dz", "zmid", "zbot", "kmax", "lat", "temp", "salt", "sw", "dust", "fesed",
+                                                   "dms", "dmsp", "prot", "poly", "lip")}
+    syn["tracers"] = {k: cat(lambda p, k=k: p["tracers"][k]) for k in parts[0]["tracers"]}
+    syn["forcing"] = {k: cat(lambda p, k=k: p["forcing"][k]) for k in parts[0]["forcing"]}
+    for k in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux"):
+        syn[k] = np.concatenate([p[k] for p in parts], axis=1)
+    return syn
+
+
+def run_all(R, syn, tag):
+    out = {}
+    tr = synth.bgc_tracer_array(syn)
+    nc, nz = syn["temp"].shape
+    out["in.bgc_tracers"] = tr
+    for k in ("temp", "salt", "zmid", "dz", "zbot", "lat", "kmax", "fesed", "dust", "sw"):
+        out["in." + k] = syn[k]
+    z = np.zeros((nc, nz))
+    a = R.bgc_source_sink(tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
+                          syn["fesed"], syn["dust"], syn["sw"], z, z, alt_co2_use_eco=True, diag_init=-7.0)
+
+    def put(prefix, res):
+        out[prefix + ".tend"] = res["tend"]
+        out[prefix + ".ph_prev"] = res["ph_prev"]
+        out[prefix + ".ph_prev_alt"] = res["ph_prev_alt"]
+        for g in ("kc", "kca", "ca", "c"):
+            for nm, v in res[g].items():
+                out["%s.%s.%s" % (prefix, g, nm)] = v
+
+    put("bgc_cold", a)
+    # warm call: perturbed tracers, previous pH as bracket centre, alt_co2_use_eco off
+    tr2 = tr * (1.0 + 1.0e-3 * np.sin(np.arange(tr.size).reshape(tr.shape)))
+    out["in.bgc_tracers_warm"] = tr2
+    b = R.bgc_source_sink(tr2, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
+                          syn["fesed"], syn["dust"], syn["sw"], a["ph_prev"], a["ph_prev_alt"] + 0.01 * (a["ph_prev_alt"] != 0),
+                          alt_co2_use_eco=False, diag_init=-7.0)
+    put("bgc_warm", b)
+    # surface fluxes, cold then warm
+    f = syn["forcing"]
+    for nm, v in f.items():
+        out["in.forcing." + nm] = v
+    for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux"):
+        out["in." + nm] = syn[nm]
+    s1 = R.bgc_surface_fluxes(tr, f, syn["depositionFlux"], syn["riverFlux"], syn["gasFlux"], syn["seaIceFlux"], diag_init=-7.0)
+    s2 = R.bgc_surface_fluxes(tr2, s1["forcing"], s1["depositionFlux"], s1["riverFlux"], s1["gasFlux"], s1["seaIceFlux"],
+                              diag_init=-7.0)
+    for pre, s in (("surf_cold", s1), ("surf_warm", s2)):
+        for nm, v in s["forcing"].items():
+            out["%s.forcing.%s" % (pre, nm)] = v
+        for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux", "netFlux"):
+            out["%s.%s" % (pre, nm)] = s[nm]
+        for nm, v in s["fdiag"].items():
+            out["%s.fdiag.%s" % (pre, nm)] = v
+    # DMS / MACROS
+    dtr = synth.dms_tracer_array(syn)
+    out["in.dms_tracers"] = dtr
+    d = R.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"], diag_init=-7.0)
+    out["dms.tend"] = d["tend"]
+    for nm, v in d["kc"].items():
+        out["dms.kc." + nm] = v
+    ds = R.dms_surface_fluxes(dtr, f, diag_init=-7.0)
+    out["dms_surf.netFlux"] = ds["netFlux"]
+    for nm, v in ds["forcing"].items():
+        out["dms_surf.forcing." + nm] = v
+    for nm, v in ds["fdiag"].items():
+        out["dms_surf.fdiag." + nm] = v
+    mtr = synth.macros_tracer_array(syn)
+    out["in.macros_tracers"] = mtr
+    m = R.macros_source_sink(mtr, syn["kmax"], diag_init=-7.0)
+    out["macros.tend"] = m["tend"]
+    for nm, v in m["kc"].items():
+        out["macros.kc." + nm] = v
+    path = os.path.join(HERE, tag + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
+
+
+def kat(R):
+    out = {}
+    nz, nc = 2, 1
+    syn = gather(60, [0])
+    tr = synth.bgc_tracer_array(syn)
+    f = {k: v.copy() for k, v in syn["forcing"].items()}
+    f["SST"][:] = 10.0
+    f["SSS"][:] = 35.0
+    f["surfacePressure"][:] = 1.0
+    s = R.bgc_surface_fluxes(tr, f, syn["depositionFlux"], syn["riverFlux"], syn["gasFlux"], syn["seaIceFlux"])
+    out["O2SAT_10C_35psu"] = s["fdiag"]["O2SAT"]
+    out["SCHMIDT_O2_10C"] = s["fdiag"]["SCHMIDT_O2"]
+    out["SCHMIDT_CO2_10C"] = s["fdiag"]["SCHMIDT_CO2"]
+    # carbonate terms on a grid (k=1 surface and k>1 interior with pressure factors)
+    T, S, D, K = np.meshgrid(np.array([-1.8, 2.0, 10.0, 20.0, 30.0]), np.array([0.05, 20.0, 33.0, 35.0, 37.0]),
+                             np.array([5.0, 150.0, 1000.0, 4500.0]), np.array([1, 2, 40]), indexing="ij")
+    T, S, D, K = (x.ravel() for x in (T, S, D, K))
+    n = T.size
+    dic = 2000.0 + 0.5 * np.arange(n) % 300
+    ta = 2300.0 + 0.25 * np.arange(n) % 100
+    pt = 0.1 + 0.01 * (np.arange(n) % 200)
+    sit = 1.0 + 0.5 * (np.arange(n) % 150)
+    lo, hi = np.full(n, 6.0), np.full(n, 9.0)
+    c3 = R.comp_co3terms(K.astype(np.int32), D, T, S, dic, ta, pt, sit, lo, hi)
+    sat = R.comp_co3_sat_vals(K.astype(np.int32), D, T, S)
+    lo2, hi2 = c3["ph"] - 0.2, c3["ph"] + 0.2
+    c3w = R.comp_co3terms(K.astype(np.int32), D, T, S, dic, ta, pt, sit, lo2, hi2)
+    # a bracket that does not contain the root -> exercises the grow loop (co2calc.F90:920-938)
+    c3g = R.comp_co3terms(K.astype(np.int32), D, T, S, dic, ta, pt, sit, np.full(n, 8.9), np.full(n, 9.0))
+    one = R.co2calc_1point(D, T, S, dic, ta, pt, sit, np.full(n, 7.0), np.full(n, 9.0), np.full(n, 400.0), np.full(n, 1.0))
+    out.update({"grid.k": K, "grid.depth": D, "grid.temp": T, "grid.salt": S, "grid.dic": dic, "grid.ta": ta,
+                "grid.pt": pt, "grid.sit": sit})
+    for nm, v in c3.items():
+        out["co3terms_cold." + nm] = v
+    for nm, v in c3w.items():
+        out["co3terms_warm." + nm] = v
+    for nm, v in c3g.items():
+        out["co3terms_grow." + nm] = v
+    for nm, v in sat.items():
+        out["co3_sat." + nm] = v
+    for nm, v in one.items():
+        out["co2calc_1point." + nm] = v
+    path = os.path.join(HERE, "kat.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
+
+
+def main():
+    assert refbind.available(), "build the reference first: make -C oracle ref"
+    R = refbind.Ref()
+    run_all(R, gather(60, [0]), "config1_1x60")
+    cols = pick_columns(60, 24)
+    print("branch columns (nz=60):", cols)
+    run_all(R, gather(60, cols), "branch_cols_60")
+    cols = pick_columns(100, 8)
+    print("branch columns (nz=100):", cols)
+    run_all(R, gather(100, cols), "branch_cols_100")
+    kat(R)
+    # parameter tables + names (pins *_parms_init / *_init)
+    p = R.bgc_get_params()
+    names = R.bgc_names()
+    np.savez_compressed(os.path.join(HERE, "params.npz"), areal=p["areal"], aint=p["aint"], parms=p["parms"],
+                        scalelen_z=p["scalelen_z"], scalelen_vals=p["scalelen_vals"], consts=p["consts"],
+                        dms_parms=R.dms_get_parms(), macros_parms=R.macros_get_parms(),
+                        bgc_names=np.array(names), dms_names=np.array(R.dms_names()),
+                        macros_names=np.array(R.macros_names()))
+    with open(os.path.join(HERE, "PROVENANCE.txt"), "w") as fh:
+        fh.write("generated by tests/golden/make_golden.py from oracle/_ref/libbgc_ref.so\n")
+        fh.write(open(os.path.join(ROOT, "oracle", "_ref", "BUILD_INFO.txt")).read())
+        fh.write("synthetic seed 0x%X\n" % int(synth.SEED))
+
+
+if __name__ == "__main__":
+    main()
