@@ -1,0 +1,301 @@
+/* libobgc -- C ABI of the MI355X-native ocean-BGC column engine.
+ *
+ * This is the drop-in boundary for the hot path of E3SM-Project/Ocean-BGC: every
+ * compute entry point below replaces one public Fortran subroutine of the
+ * reference (which has no FFI layer of its own -- its boundary is the Fortran
+ * module API).  The thin Fortran modules in ocean-bgc_amd/fortran/
+ * keep the reference's module and procedure names and forward to these functions
+ * through ISO_C_BINDING; INTEGRATION.md shows the binding.
+ *
+ *   reference subroutine (file:line)                      C entry point
+ *   BGC_parms_init      BGC_parms.F90:497   + BGC_init BGC_mod.F90:184   obgc_bgc_params_init
+ *   BGC_SourceSink      BGC_mod.F90:340-342                               obgc_bgc_source_sink
+ *   BGC_SurfaceFluxes   BGC_mod.F90:2706-2708                             obgc_bgc_surface_fluxes
+ *   DMS_parms_init      DMS_parms.F90:203   + DMS_init DMS_mod.F90:73     obgc_dms_params_init
+ *   DMS_SourceSink      DMS_mod.F90:156-157                               obgc_dms_source_sink
+ *   DMS_SurfaceFluxes   DMS_mod.F90:778-780                               obgc_dms_surface_fluxes
+ *   MACROS_parms_init   MACROS_parms.F90:143 + MACROS_init MACROS_mod.F90:72  obgc_macros_params_init
+ *   MACROS_SourceSink   MACROS_mod.F90:137-138                            obgc_macros_source_sink
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, POD structs; no exceptions cross the boundary.
+ *  - every function returns 0 (OBGC_OK) or a negative obgc_status; the reference
+ *    itself cannot fail (its aborts are commented out, co2calc.F90:931-933, 993-995),
+ *    so a non-zero status always means an engine problem (no GPU, bad argument,
+ *    out of device memory), never a numerical one.  There is NO CPU fallback.
+ *  - indices inside parameter structs are 1-based, like the reference's *_ind.
+ *  - arrays are fp64; integers are 32-bit (BGC_r8 / BGC_i4, BGC_parms.F90:21-24).
+ *  - the caller owns every array; the engine owns only scratch inside the handle and
+ *    keeps no pointer after a call returns.  State carried between calls lives in the
+ *    caller's arrays exactly as in the reference (PH_PREV_3D, PH_PREV_ALT_CO2_3D,
+ *    surface_pH, surface_pH_alt_co2; BGC_parms.F90:151-152, 170-171).
+ *  - one handle per host thread per GPU.  Calls are synchronous unless the handle was
+ *    created with OBGC_ASYNC (then obgc_sync completes them).
+ */
+#ifndef OBGC_H
+#define OBGC_H
+
+#include "obgc_fields.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBGC_ABI_VERSION 1
+#define OBGC_AUTOTROPH_CNT 4   /* BGC_parms.F90:42-43 */
+#define OBGC_BGC_NTRACER 30    /* BGC_mod.F90:117-118 */
+#define OBGC_DMS_NTRACER 14    /* DMS_mod.F90:61-62 */
+#define OBGC_MACROS_NTRACER 8  /* MACROS_mod.F90 MACROS_tracer_cnt */
+
+typedef enum {
+  OBGC_OK = 0,
+  OBGC_ERR_INVALID = -1,     /* null / inconsistent argument */
+  OBGC_ERR_NO_DEVICE = -2,   /* no usable gfx950 device */
+  OBGC_ERR_HIP = -3,         /* a HIP runtime call failed (see obgc_last_error) */
+  OBGC_ERR_ALLOC = -4,       /* device or pinned-host allocation failed */
+  OBGC_ERR_UNSUPPORTED = -5
+} obgc_status;
+
+/* Memory layout of level-dependent arrays.
+ *  KFAST   = the reference's Fortran order X(k, column[, n]): k fastest, then column,
+ *            then tracer/autotroph plane (BGC_parms.F90:128-132).
+ *  COLFAST = the engine's native order X[n][k][column]: column fastest.  A host that
+ *            keeps its tracers resident on the GPU should use this one: all kernels
+ *            then read and write fully coalesced rows. */
+typedef enum { OBGC_LAYOUT_KFAST = 0, OBGC_LAYOUT_COLFAST = 1 } obgc_layout;
+typedef enum { OBGC_MEM_HOST = 0, OBGC_MEM_DEVICE = 1 } obgc_memspace;
+
+enum { OBGC_ASYNC = 1u };      /* obgc_create flag: device-memory calls return after enqueue */
+
+/* Shape of one call.  For KFAST `ld` is the element distance between consecutive
+ * columns (>= nlev; the reference's numLevelsMax) and `plane` the distance between
+ * tracer / autotroph planes (>= ld*ncol; ld*numColumnsMax when the host array is
+ * larger than the batch).  For COLFAST `ld` is the distance between consecutive
+ * levels (>= ncol) and `plane` the distance between planes (>= ld*nlev).
+ * plane == 0 selects the dense default. (column) and (column,n) arrays are always
+ * column-fastest with plane stride `ldc` (>= ncol; 0 = ncol). */
+typedef struct {
+  int nlev;        /* numLevelsMax */
+  int ncol;        /* numColumns   */
+  int layout;      /* obgc_layout  */
+  int memspace;    /* obgc_memspace of EVERY array pointer of the call */
+  long long ld;
+  long long plane;
+  long long ldc;
+} obgc_grid;
+
+/* ---------------------------------------------------------------- parameters */
+
+/* autotroph_type, BGC_parms.F90:51-79 (character names are host-side only) */
+typedef struct {
+#define X(n) int n;
+  OBGC_AUTOTROPH_INTS(X)
+#undef X
+#define X(n) double n;
+  OBGC_AUTOTROPH_REALS(X)
+#undef X
+} obgc_autotroph;
+
+typedef struct {
+  obgc_autotroph autotrophs[OBGC_AUTOTROPH_CNT];
+  int ind[OBGC_BGC_NTRACER];                 /* tracer slots, order OBGC_BGC_TRACERS */
+  int sp_ind, diat_ind, diaz_ind, phaeo_ind; /* BGC_parms.F90:114-118 */
+#define X(n) double n;
+  OBGC_BGC_PARMS(X)
+#undef X
+  double parm_scalelen_z[4], parm_scalelen_vals[4]; /* BGC_parms.F90:363-365 */
+  double T0_Kelvin_BGC;                      /* BGC_parms.F90:45 (host-set global) */
+  int lrest_po4, lrest_no3, lrest_sio3;      /* BGC_mod.F90:131-134; must be 0 (never set in the reference) */
+} obgc_bgc_params;
+
+typedef struct {
+  int ind[OBGC_DMS_NTRACER];                 /* order OBGC_DMS_TRACERS */
+#define X(n) double n;
+  OBGC_DMS_PARMS(X)
+#undef X
+} obgc_dms_params;
+
+typedef struct {
+  int ind[OBGC_MACROS_NTRACER];              /* order OBGC_MACROS_TRACERS */
+#define X(n) double n;
+  OBGC_MACROS_PARMS(X)
+#undef X
+} obgc_macros_params;
+
+/* Defaults of BGC_parms_init (BGC_parms.F90:497-699) followed by BGC_init's
+ * derivation of Chl_ind/C_ind/Fe_ind/Si_ind/CaCO3_ind (BGC_mod.F90:271-321).
+ * `ind` = 30 one-based slots in OBGC_BGC_TRACERS order, or NULL for 1..30. */
+void obgc_bgc_params_init(obgc_bgc_params *p, const int *ind, double T0_Kelvin_BGC);
+/* re-derive the autotroph tracer slots after editing ind[] / kSiO3 / *_calcifier */
+void obgc_bgc_params_derive(obgc_bgc_params *p);
+void obgc_dms_params_init(obgc_dms_params *p, const int *ind);       /* DMS_parms.F90:203-241 */
+void obgc_macros_params_init(obgc_macros_params *p, const int *ind); /* MACROS_parms.F90:143-162 */
+/* tracer metadata of BGC_init / DMS_init / MACROS_init (BGC_mod.F90:221-328,
+ * DMS_mod.F90:101-143, MACROS_mod.F90:72-129). which: 0 short_name, 1 long_name, 2 units;
+ * module: 0 BGC, 1 DMS, 2 MACROS; slot is 1-based in the module's OBGC_*_TRACERS order.
+ * Returns a static string, or NULL when out of range. */
+const char *obgc_tracer_name(int module, int slot, int which);
+
+/* ------------------------------------------------------------------- handle */
+
+typedef struct obgc_handle obgc_handle;
+
+int obgc_abi_version(void);
+int obgc_sizeof_bgc_params(void);
+int obgc_sizeof_dms_params(void);
+int obgc_sizeof_macros_params(void);
+int obgc_sizeof_bgc_diag(void);
+int obgc_create(obgc_handle **h, int device_id, unsigned flags);
+int obgc_destroy(obgc_handle *h);
+int obgc_sync(obgc_handle *h);
+const char *obgc_last_error(const obgc_handle *h);
+/* upload parameters (the reference's mutable module variables); call again whenever
+ * the host changes one.  obgc_create installs the defaults. */
+int obgc_set_bgc_params(obgc_handle *h, const obgc_bgc_params *p);
+int obgc_set_dms_params(obgc_handle *h, const obgc_dms_params *p);
+int obgc_set_macros_params(obgc_handle *h, const obgc_macros_params *p);
+/* HIP stream (hipStream_t) the engine enqueues its last kernel of a call on */
+void *obgc_stream(obgc_handle *h);
+/* device time of the kernels of the last *_source_sink / *_surface_fluxes call in ms
+ * (HIP events on the engine's own streams); `which`: 0 whole call, 1 carbonate
+ * kernel, 2 ecosystem column-sweep kernel, 3 layout transposes */
+double obgc_last_kernel_ms(obgc_handle *h, int which);
+
+/* --------------------------------------------------------- BGC_SourceSink */
+
+/* BGC_diagnostics_type (BGC_parms.F90:192-321) as a struct of pointers.  NULL members
+ * are skipped.  (k,column,autotroph) arrays use grid.plane between autotroph planes;
+ * (column,autotroph) arrays use grid.ldc.  POC_ACCUM, DONr_remin, DOPr_remin are never
+ * written (the reference never touches them either). */
+typedef struct {
+#define X(n) double *n;
+  OBGC_BGC_DIAG_KC(X)
+  OBGC_BGC_DIAG_KCA(X)
+  OBGC_BGC_DIAG_CA(X)
+  OBGC_BGC_DIAG_C(X)
+#undef X
+} obgc_bgc_diag;
+
+typedef struct {
+  obgc_grid grid;
+  /* BGC_input_type, BGC_parms.F90:127-137 */
+  const double *tracers;      /* BGC_tracers(k,column,30) */
+  const double *temp, *salt;  /* PotentialTemperature, Salinity (k,column) */
+  const double *zmid, *dz, *zbot; /* cell_center_depth, cell_thickness, cell_bottom_depth [cm] */
+  const double *lat;          /* cell_latitude(column) */
+  const int *kmax;            /* number_of_active_levels(column) */
+  /* BGC_forcing_type, BGC_parms.F90:139-145 */
+  const double *fesedflux;    /* FESEDFLUX(k,column) */
+  const double *dust_flux_in; /* dust_FLUX_IN(column) */
+  const double *sw_flux;      /* ShortWaveFlux_surface(column) */
+  /* BGC_output_type, BGC_parms.F90:167-172 */
+  double *tend;               /* BGC_tendencies(k,column,30), fully overwritten */
+  double *ph_prev;            /* PH_PREV_3D(k,column), inout, 0 = no previous solution */
+  double *ph_prev_alt;        /* PH_PREV_ALT_CO2_3D(k,column), inout */
+  const obgc_bgc_diag *diag;  /* NULL = no diagnostics */
+  int alt_co2_use_eco;        /* BGC_mod.F90:1741-1745 */
+} obgc_bgc_source_sink_args;
+
+int obgc_bgc_source_sink(obgc_handle *h, const obgc_bgc_source_sink_args *a);
+
+/* ------------------------------------------------------ BGC_SurfaceFluxes */
+
+typedef struct {
+#define X(n) double *n;
+  OBGC_BGC_FLUX_DIAG(X)
+#undef X
+} obgc_bgc_flux_diag;
+
+typedef struct {
+  obgc_grid grid;             /* shape of `tracers`; only level 1 is read (BGC_mod.F90:2816-2822) */
+  const double *tracers;
+  /* BGC_forcing_type (column) members, BGC_parms.F90:143-155 */
+  const double *surfacePressure, *windSpeedSquared10m, *atmCO2, *atmCO2_ALT_CO2, *surfaceDepth, *SST, *SSS;
+  double *iceFraction;        /* clamped to [0,1] IN PLACE (BGC_mod.F90:2837-2838) */
+  double *surface_pH, *surface_pH_alt_co2; /* inout */
+  /* (column,30) arrays, plane stride grid.ldc; the Fe rows of the first four are scaled
+   * by parm_Fe_bioavail IN PLACE on every call (BGC_mod.F90:2828-2835) */
+  double *depositionFlux, *riverFlux, *gasFlux, *seaIceFlux;
+  double *netFlux;            /* out */
+  const obgc_bgc_flux_diag *diag; /* NULL = none; the reference zero-fills all 14 first */
+  int lcalc_O2_gas_flux, lcalc_CO2_gas_flux; /* BGC_parms.F90:162-164 */
+} obgc_bgc_surface_fluxes_args;
+
+int obgc_bgc_surface_fluxes(obgc_handle *h, const obgc_bgc_surface_fluxes_args *a);
+
+/* -------------------------------------------------------------------- DMS */
+
+typedef struct {
+#define X(n) double *n;
+  OBGC_DMS_DIAG_KC(X)
+#undef X
+} obgc_dms_diag;
+
+typedef struct {
+  obgc_grid grid;
+  const double *tracers;      /* DMS_tracers(k,column,14), DMS_parms.F90:85-87 */
+  const double *dz;           /* cell_thickness(k,column) */
+  const int *kmax;
+  const double *SST, *sw_flux; /* DMS_forcing_type (column), DMS_parms.F90:95-101 */
+  double *tend;               /* DMS_tendencies(k,column,14) */
+  const obgc_dms_diag *diag;  /* NULL = none.  NOT zero-filled (the reference does not either) */
+} obgc_dms_source_sink_args;
+
+int obgc_dms_source_sink(obgc_handle *h, const obgc_dms_source_sink_args *a);
+
+typedef struct {
+#define X(n) double *n;
+  OBGC_DMS_FLUX_DIAG(X)
+#undef X
+} obgc_dms_flux_diag;
+
+typedef struct {
+  obgc_grid grid;
+  const double *tracers;
+  const double *surfacePressure, *windSpeedSquared10m, *SST, *SSS;
+  double *iceFraction;        /* clamped in place, DMS_mod.F90:858-859 */
+  double *netFlux;            /* (column,14): only the dms and dmsp rows are written */
+  const obgc_dms_flux_diag *diag;
+  int lcalc_DMS_gas_flux;     /* 0: the call is a no-op, DMS_mod.F90:846 */
+} obgc_dms_surface_fluxes_args;
+
+int obgc_dms_surface_fluxes(obgc_handle *h, const obgc_dms_surface_fluxes_args *a);
+
+/* ----------------------------------------------------------------- MACROS */
+
+typedef struct {
+#define X(n) double *n;
+  OBGC_MACROS_DIAG_KC(X)
+#undef X
+} obgc_macros_diag;
+
+typedef struct {
+  obgc_grid grid;
+  const double *tracers;      /* MACROS_tracers(k,column,8) */
+  const int *kmax;
+  double *tend;               /* MACROS_tendencies(k,column,8) */
+  const obgc_macros_diag *diag;
+} obgc_macros_source_sink_args;
+
+int obgc_macros_source_sink(obgc_handle *h, const obgc_macros_source_sink_args *a);
+
+/* ----------------------------------------------- workload utilities (bench/tests)
+ * Deterministic synthetic columns, generated on the device in the
+ * engine's native COLFAST layout for global columns [col0, col0+ncol).  Bit-identical
+ * to ocean-bgc_amd/synth.py.  All pointers are DEVICE pointers; NULL skips a field.
+ * `tracers` receives 30 planes placed by `ind` (1-based, OBGC_BGC_TRACERS order). */
+typedef struct {
+  int nlev, ncol;
+  long long col0;
+  long long ld, plane, ldc;
+  const int *ind;             /* HOST pointer to 30 ints, or NULL for 1..30 */
+  double *tracers, *temp, *salt, *zmid, *dz, *zbot, *fesedflux;
+  double *lat, *dust_flux_in, *sw_flux;
+  int *kmax;
+} obgc_synth_args;
+int obgc_synth_fill(obgc_handle *h, const obgc_synth_args *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

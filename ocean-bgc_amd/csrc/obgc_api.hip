@@ -1,0 +1,679 @@
+// Host side of libobgc: handle, parameter tables, argument marshalling, stream layout.
+// There is no CPU compute path in this library: every entry point either launches the
+// HIP kernels or returns a negative status.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "obgc_internal.h"
+
+using namespace obgc;
+
+struct obgc_handle {
+  int device = 0;
+  unsigned flags = 0;
+  hipStream_t s_main = nullptr;   // column-sweep kernels, copies, transposes
+  hipStream_t s_aux = nullptr;    // cell-parallel carbonate kernel runs beside the sweep
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
+             ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr;
+  bool timed_valid = false, tr_valid = false;
+  obgc_bgc_params bgc;
+  obgc_dms_params dms;
+  obgc_macros_params macros;
+  // device scratch: one growing arena, carved per call
+  char* arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  std::string err;
+};
+
+namespace {
+
+constexpr double kDps = 1.0 / 86400.0;
+
+int fail(obgc_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, call)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(h, OBGC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+// ---- scratch arena ---------------------------------------------------------------------
+int arena_reserve(obgc_handle* h, size_t bytes) {
+  if (bytes <= h->arena_bytes) return OBGC_OK;
+  HIP_TRY(h, hipStreamSynchronize(h->s_main));
+  HIP_TRY(h, hipStreamSynchronize(h->s_aux));
+  if (h->arena) (void)hipFree(h->arena);
+  h->arena = nullptr;
+  h->arena_bytes = 0;
+  size_t want = bytes + bytes / 8;
+  if (hipMalloc((void**)&h->arena, want) != hipSuccess) {
+    if (hipMalloc((void**)&h->arena, bytes) != hipSuccess)
+      return fail(h, OBGC_ERR_ALLOC, "device scratch allocation of " + std::to_string(bytes) + " bytes failed");
+    want = bytes;
+  }
+  h->arena_bytes = want;
+  return OBGC_OK;
+}
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// A staged copy of one caller array (host memspace): device twin + copy directions.
+struct Stage {
+  void* dev;
+  void* host;
+  size_t bytes;
+  bool in, out;
+};
+
+struct Stager {
+  obgc_handle* h;
+  bool host;            // caller arrays are host memory
+  std::vector<Stage> items;
+  size_t need = 0;
+  explicit Stager(obgc_handle* hh, bool is_host) : h(hh), host(is_host) {}
+  // pass 1: register; returns an index
+  int add(const void* p, size_t bytes, bool in, bool out) {
+    if (!p) return -1;
+    items.push_back(Stage{nullptr, const_cast<void*>(p), bytes, in, out});
+    need += align_up(bytes);
+    return (int)items.size() - 1;
+  }
+  template <class T>
+  T* dev(int i) const { return i < 0 ? nullptr : (T*)items[(size_t)i].dev; }
+};
+
+// ---- parameter tables ----------------------------------------------------------------------
+void set_autotroph(obgc_autotroph& a, int nfix, int impc, int grazee, int tfn, const double (&v)[30]) {
+  a.Nfixer = nfix; a.imp_calcifier = impc; a.exp_calcifier = 0; a.grazee_ind = grazee; a.temp_function = tfn;
+  a.Chl_ind = a.C_ind = a.Fe_ind = a.Si_ind = a.CaCO3_ind = 0;
+  double* d = &a.kFe;   // the 30 reals are contiguous in OBGC_AUTOTROPH_REALS order
+  for (int i = 0; i < 30; ++i) d[i] = v[i];
+}
+
+const char* kBgcShort[30] = {"PO4", "NO3", "SiO3", "NH4", "Fe", "O2", "DIC", "DIC_ALT_CO2", "ALK", "DOC", "DON", "DOFe",
+                             "DOP", "DOPr", "DONr", "zooC", "spC", "spChl", "spFe", "spCaCO3", "diatC", "diatChl",
+                             "diatFe", "diatSi", "phaeoC", "phaeoChl", "phaeoFe", "diazC", "diazChl", "diazFe"};
+const char* kBgcLong[30] = {"Dissolved Inorganic Phosphate", "Dissolved Inorganic Nitrate", "Dissolved Inorganic Silicate",
+                            "Dissolved Ammonia", "Dissolved Inorganic Iron", "Dissolved Oxygen", "Dissolved Inorganic Carbon",
+                            "Dissolved Inorganic Carbon, Alternative CO2", "Alkalinity", "Dissolved Organic Carbon",
+                            "Dissolved Organic Nitrogen", "Dissolved Organic Iron", "Dissolved Organic Phosphorus",
+                            "Refractory DOP", "Refractory DON", "Zooplankton Carbon", "Small Phyto Carbon",
+                            "Small Phyto Chlorophyll", "Small Phyto Iron", "Small Phyto CaCO3", "Diatom Carbon",
+                            "Diatom Chlorophyll", "Diatom Iron", "Diatom Silicon", "Phaeocystis Carbon",
+                            "Phaeocystis Chlorophyll", "Phaeocystis Iron", "Diazotroph Carbon", "Diazotroph Chlorophyll",
+                            "Diazotroph Iron"};
+const char* kDmsShort[14] = {"DMS", "DMSP", "NO3", "DOC", "zooC", "spC", "spCaCO3", "diatC", "diazC", "phaeoC", "spChl",
+                             "diatChl", "diazChl", "phaeoChl"};
+const char* kDmsLong[14] = {"DiMethyl Sulfide", "Dimethylsulfoniopropionate", "Dissolved Inorganic Nitrate",
+                            "Dissolved Organic Carbon", "Zooplankton Carbon", " Small Phytoplankton Carbon",
+                            " Small Phytoplankton Calcium Carbonate", " Diatom Carbon", " Diazotroph Carbon",
+                            "Phaeocystis Carbon", " Small Phytoplankton Chlorophyll", " Diatom Chlorophyll",
+                            " Diazotroph Chlorophyll", "Phaeocystis Chlorophyll"};
+const char* kMacShort[8] = {"PROT", "POLY", "LIP", "zooC", "spC", "diatC", "diazC", "phaeoC"};
+const char* kMacLong[8] = {"Proteins", "Polysaccharides", "Lipids", "Zooplankton Carbon", " Small Phytoplankton Carbon",
+                           " Diatom Carbon", " Diazotroph Carbon", "Phaeocystis Carbon"};
+
+bool grid_ok(const obgc_grid& g) {
+  if (g.nlev < 1 || g.ncol < 0) return false;
+  if (g.layout != OBGC_LAYOUT_KFAST && g.layout != OBGC_LAYOUT_COLFAST) return false;
+  if (g.memspace != OBGC_MEM_HOST && g.memspace != OBGC_MEM_DEVICE) return false;
+  const long long minld = (g.layout == OBGC_LAYOUT_KFAST) ? g.nlev : g.ncol;
+  if (g.ld != 0 && g.ld < minld) return false;
+  if (g.ldc != 0 && g.ldc < g.ncol) return false;
+  return true;
+}
+
+// bytes spanned by `nplanes` planes of a (k,column) array
+size_t span_kc(const GridView& v, int nplanes) {
+  const long long last = v.at(v.nlev - 1, v.ncol > 0 ? v.ncol - 1 : 0) + 1;
+  return (size_t)((long long)(nplanes - 1) * v.plane + last) * sizeof(double);
+}
+size_t span_c(const GridView& v, int nplanes) {
+  return (size_t)((long long)(nplanes - 1) * v.ldc + v.ncol) * sizeof(double);
+}
+
+int stage_in(obgc_handle* h, Stager& st) {
+  if (!st.host) {
+    for (auto& it : st.items) it.dev = it.host;
+    return OBGC_OK;
+  }
+  int rc = arena_reserve(h, h->arena_used + st.need);
+  if (rc != OBGC_OK) return rc;
+  size_t off = h->arena_used;
+  for (auto& it : st.items) {
+    it.dev = h->arena + off;
+    off += align_up(it.bytes);
+    if (it.in) HIP_TRY(h, hipMemcpyAsync(it.dev, it.host, it.bytes, hipMemcpyHostToDevice, h->s_main));
+  }
+  h->arena_used = off;
+  return OBGC_OK;
+}
+
+int stage_out(obgc_handle* h, Stager& st) {
+  if (!st.host) return OBGC_OK;
+  for (auto& it : st.items)
+    if (it.out) HIP_TRY(h, hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, h->s_main));
+  HIP_TRY(h, hipStreamSynchronize(h->s_main));
+  return OBGC_OK;
+}
+
+int finish(obgc_handle* h, bool force_sync) {
+  if (force_sync || !(h->flags & OBGC_ASYNC)) HIP_TRY(h, hipStreamSynchronize(h->s_main));
+  return OBGC_OK;
+}
+
+}  // namespace
+
+// ============================================================================ parameters ==
+
+extern "C" void obgc_bgc_params_derive(obgc_bgc_params* p) {   // BGC_mod.F90:271-321
+  enum { spC = 16, spChl, spFe, spCaCO3, diatC, diatChl, diatFe, diatSi, phaeoC, phaeoChl, phaeoFe, diazC, diazChl, diazFe };
+  for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) {
+    obgc_autotroph& at = p->autotrophs[a];
+    const int ai = a + 1;
+    if (ai == p->sp_ind) { at.Chl_ind = p->ind[spChl]; at.C_ind = p->ind[spC]; at.Fe_ind = p->ind[spFe]; }
+    else if (ai == p->diat_ind) { at.Chl_ind = p->ind[diatChl]; at.C_ind = p->ind[diatC]; at.Fe_ind = p->ind[diatFe]; }
+    else if (ai == p->diaz_ind) { at.Chl_ind = p->ind[diazChl]; at.C_ind = p->ind[diazC]; at.Fe_ind = p->ind[diazFe]; }
+    else if (ai == p->phaeo_ind) { at.Chl_ind = p->ind[phaeoChl]; at.C_ind = p->ind[phaeoC]; at.Fe_ind = p->ind[phaeoFe]; }
+    at.Si_ind = (at.kSiO3 > 0.0) ? p->ind[diatSi] : 0;
+    at.CaCO3_ind = (at.imp_calcifier || at.exp_calcifier) ? p->ind[spCaCO3] : 0;
+  }
+}
+
+extern "C" void obgc_bgc_params_init(obgc_bgc_params* p, const int* ind, double T0K) {
+  std::memset(p, 0, sizeof(*p));
+  for (int i = 0; i < OBGC_BGC_NTRACER; ++i) p->ind[i] = ind ? ind[i] : i + 1;
+  p->sp_ind = 1; p->diat_ind = 2; p->diaz_ind = 3; p->phaeo_ind = 4;
+  p->T0_Kelvin_BGC = T0K;
+  // namelist defaults, BGC_parms.F90:524-541
+  p->parm_Fe_bioavail = 1.0; p->parm_o2_min = 4.0; p->parm_o2_min_delta = 2.0; p->parm_kappa_nitrif = 0.06 * kDps;
+  p->parm_nitrif_par_lim = 1.0; p->parm_z_mort_0 = 0.1 * kDps; p->parm_z_mort2_0 = 0.4 * kDps;
+  p->parm_labile_ratio = 0.85; p->parm_POMbury = 1.4; p->parm_BSIbury = 0.65; p->parm_fe_scavenge_rate0 = 3.0;
+  p->parm_f_prod_sp_CaCO3 = 0.055; p->parm_POC_diss = 88.0e2; p->parm_SiO2_diss = 250.0e2; p->parm_CaCO3_diss = 150.0e2;
+  const double sz[4] = {130.0e2, 290.0e2, 670.0e2, 1700.0e2}, sv[4] = {1.0, 3.0, 5.0, 9.0};
+  for (int i = 0; i < 4; ++i) { p->parm_scalelen_z[i] = sz[i]; p->parm_scalelen_vals[i] = sv[i]; }
+  // autotroph table, BGC_parms.F90:543-697.  Columns: kFe kPO4 kDOP kNO3 kNH4 kSiO3 Qp gQfe_0 gQfe_min alphaPI PCref
+  // thetaN_max loss_thres loss_thres2 temp_thres temp_thresS temp_thresN temp_optN temp_optS mort mort2 agg_rate_max
+  // agg_rate_min z_umax_0 z_grz graze_zoo graze_poc graze_doc loss_poc f_zoo_detr
+  const double sp[30] = {0.04e-3, 0.01, 0.26, 0.1, 0.01, 0.0, 0.00855, 20.0e-6, 3.0e-6, 0.6 * kDps, 5.5 * kDps, 2.5, 0.04,
+                         0.0, -20.0, -20.0, -20.0, 50.0, 50.0, 0.12 * kDps, 0.001 * kDps, 0.9, 0.01, 3.3 * kDps, 1.05, 0.3,
+                         0.0, 0.15, 0.0, 0.15};
+  const double diat[30] = {0.06e-3, 0.05, 0.9, 0.5, 0.05, 0.8, 0.00855, 20.0e-6, 3.0e-6, 0.465 * kDps, 5.5 * kDps, 4.0, 0.04,
+                           0.0, -20.0, 10.0, 35.0, 16.3, 5.0, 0.12 * kDps, 0.001 * kDps, 0.9, 0.02, 3.23 * kDps, 1.0, 0.3,
+                           0.42, 0.15, 0.0, 0.2};
+  const double diaz[30] = {0.04e-3, 0.02, 0.09, 1.0, 0.15, 0.0, 0.002735, 60.0e-6, 12.0e-6, 0.4 * kDps, 0.7 * kDps, 2.5, 0.022,
+                           0.001, 14.0, -20.0, -20.0, 50.0, 50.0, 0.15 * kDps, 0.0, 0.0, 0.0, 0.6 * kDps, 1.2, 0.3, 0.05,
+                           0.15, 0.0, 0.15};
+  const double phaeo[30] = {0.075e-3, 0.05, 0.9, 0.7, 0.05, 0.0, 0.00855, 20.0e-6, 3.0e-6, 0.77 * kDps, 5.5 * kDps, 2.5, 0.04,
+                            0.0, -20.0, 10.0, 35.0, 16.3, 5.0, 0.12 * kDps, 0.001 * kDps, 0.9, 0.02, 3.23 * kDps, 1.0, 0.3,
+                            0.42, 0.15, 0.0, 0.2};
+  set_autotroph(p->autotrophs[0], 0, 1, 1, 1, sp);
+  set_autotroph(p->autotrophs[1], 0, 0, 2, 1, diat);
+  set_autotroph(p->autotrophs[2], 1, 0, 3, 1, diaz);
+  set_autotroph(p->autotrophs[3], 0, 0, 2, 2, phaeo);   // grazed with the diatoms; quasi-MMRT temperature curve
+  obgc_bgc_params_derive(p);
+}
+
+extern "C" void obgc_dms_params_init(obgc_dms_params* p, const int* ind) {
+  std::memset(p, 0, sizeof(*p));
+  for (int i = 0; i < OBGC_DMS_NTRACER; ++i) p->ind[i] = ind ? ind[i] : i + 1;
+  p->k_S_p_base = 0.1 * kDps; p->zooC_avg = 0.3; p->mort = 0.0; p->k_conv = 1.0 * kDps; p->k_S_z = 0.1 * kDps;
+  p->B_preexp = 0.1; p->B_exp = 0.5; p->k_S_B = 30.0 * kDps; p->k_bkgnd = 0.01 * kDps; p->j_dms_perI = 0.005 * kDps;
+  p->inject_scale = 1.0; p->T_cryo_hi = 1.0; p->T_cryo_lo = -1.0; p->T_lo = 15.0; p->T_hi = 20.0;
+  p->Min_cyano_frac = 0.0; p->Max_cyano_frac = 0.5; p->Min_yld = 0.2; p->Max_yld = 0.7; p->G_phaeo_S = 0.4;
+  p->Sp_ref = 0.1; p->Stress_mult = 10.0; p->R = 0.137; p->Rs2n_diat = 0.01; p->Rs2n_phaeo = 0.3; p->Rs2n_cocco = 0.1;
+  p->Rs2n_cyano = 0.0; p->Rs2n_eukar = 0.1; p->Rs2n_diaz = 0.0; p->f_qsw_par_DMS = 0.45;
+}
+
+extern "C" void obgc_macros_params_init(obgc_macros_params* p, const int* ind) {
+  std::memset(p, 0, sizeof(*p));
+  for (int i = 0; i < OBGC_MACROS_NTRACER; ++i) p->ind[i] = ind ? ind[i] : i + 1;
+  p->f_prot = 0.6; p->f_poly = 0.2; p->f_lip = 0.2; p->k_C_p_base = kDps * 0.1; p->zooC_avg = 0.3; p->mort = 0.0;
+  p->k_prot_bac = kDps * 0.1; p->k_poly_bac = kDps * 0.01; p->k_lip_bac = kDps * 1.0; p->inject_scale = 1.0;
+}
+
+extern "C" const char* obgc_tracer_name(int module, int slot, int which) {
+  const int n = module == 0 ? 30 : module == 1 ? 14 : module == 2 ? 8 : 0;
+  if (slot < 1 || slot > n || which < 0 || which > 2) return nullptr;
+  const int i = slot - 1;
+  if (which == 2) {
+    if (module == 0) {
+      if (i == 8) return "meq/m^3";                                  // ALK, BGC_mod.F90:324
+      if (i == 17 || i == 21 || i == 25 || i == 28) return "mg/m^3";  // the four Chl tracers, 325-328
+    }
+    return "mmol/m^3";
+  }
+  if (module == 0) return which == 0 ? kBgcShort[i] : kBgcLong[i];
+  if (module == 1) return which == 0 ? kDmsShort[i] : kDmsLong[i];
+  return which == 0 ? kMacShort[i] : kMacLong[i];
+}
+
+// ================================================================================ handle ==
+
+extern "C" int obgc_abi_version(void) { return OBGC_ABI_VERSION; }
+extern "C" int obgc_sizeof_bgc_params(void) { return (int)sizeof(obgc_bgc_params); }
+extern "C" int obgc_sizeof_dms_params(void) { return (int)sizeof(obgc_dms_params); }
+extern "C" int obgc_sizeof_macros_params(void) { return (int)sizeof(obgc_macros_params); }
+extern "C" int obgc_sizeof_bgc_diag(void) { return (int)sizeof(obgc_bgc_diag); }
+
+extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
+  if (!out) return OBGC_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return OBGC_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return OBGC_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "libobgc: device %d is %s; this library carries gfx950 (MI355X) code objects only\n", device_id,
+                 prop.gcnArchName);
+    return OBGC_ERR_NO_DEVICE;
+  }
+  obgc_handle* h = new obgc_handle();
+  h->device = device_id;
+  h->flags = flags;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return OBGC_ERR_HIP;
+  }
+  hipEvent_t* evs[] = {&h->ev_begin, &h->ev_end, &h->ev_c0, &h->ev_c1, &h->ev_e0, &h->ev_e1, &h->ev_t0, &h->ev_t1, &h->ev_aux_done};
+  for (auto e : evs)
+    if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
+  obgc_bgc_params_init(&h->bgc, nullptr, 273.15);
+  obgc_dms_params_init(&h->dms, nullptr);
+  obgc_macros_params_init(&h->macros, nullptr);
+  *out = h;
+  return OBGC_OK;
+}
+
+extern "C" int obgc_destroy(obgc_handle* h) {
+  if (!h) return OBGC_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->s_main);
+  (void)hipStreamSynchronize(h->s_aux);
+  if (h->arena) (void)hipFree(h->arena);
+  hipEvent_t evs[] = {h->ev_begin, h->ev_end, h->ev_c0, h->ev_c1, h->ev_e0, h->ev_e1, h->ev_t0, h->ev_t1, h->ev_aux_done};
+  for (auto e : evs)
+    if (e) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(h->s_main);
+  (void)hipStreamDestroy(h->s_aux);
+  delete h;
+  return OBGC_OK;
+}
+
+extern "C" int obgc_sync(obgc_handle* h) {
+  if (!h) return OBGC_ERR_INVALID;
+  HIP_TRY(h, hipStreamSynchronize(h->s_aux));
+  HIP_TRY(h, hipStreamSynchronize(h->s_main));
+  return OBGC_OK;
+}
+
+extern "C" const char* obgc_last_error(const obgc_handle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" void* obgc_stream(obgc_handle* h) { return h ? (void*)h->s_main : nullptr; }
+
+extern "C" int obgc_set_bgc_params(obgc_handle* h, const obgc_bgc_params* p) {
+  if (!h || !p) return OBGC_ERR_INVALID;
+  for (int i = 0; i < OBGC_BGC_NTRACER; ++i)
+    if (p->ind[i] < 1 || p->ind[i] > OBGC_BGC_NTRACER) return fail(h, OBGC_ERR_INVALID, "BGC tracer slot out of 1..30");
+  if (p->lrest_po4 || p->lrest_no3 || p->lrest_sio3)
+    return fail(h, OBGC_ERR_UNSUPPORTED, "nutrient restoring (lrest_*) is dead code in the reference and not provided");
+  h->bgc = *p;
+  return OBGC_OK;
+}
+extern "C" int obgc_set_dms_params(obgc_handle* h, const obgc_dms_params* p) {
+  if (!h || !p) return OBGC_ERR_INVALID;
+  for (int i = 0; i < OBGC_DMS_NTRACER; ++i)
+    if (p->ind[i] < 1 || p->ind[i] > OBGC_DMS_NTRACER) return fail(h, OBGC_ERR_INVALID, "DMS tracer slot out of 1..14");
+  h->dms = *p;
+  return OBGC_OK;
+}
+extern "C" int obgc_set_macros_params(obgc_handle* h, const obgc_macros_params* p) {
+  if (!h || !p) return OBGC_ERR_INVALID;
+  for (int i = 0; i < OBGC_MACROS_NTRACER; ++i)
+    if (p->ind[i] < 1 || p->ind[i] > OBGC_MACROS_NTRACER) return fail(h, OBGC_ERR_INVALID, "MACROS tracer slot out of 1..8");
+  h->macros = *p;
+  return OBGC_OK;
+}
+
+extern "C" double obgc_last_kernel_ms(obgc_handle* h, int which) {
+  if (!h || !h->timed_valid) return -1.0;
+  if (hipEventSynchronize(h->ev_end) != hipSuccess) return -1.0;
+  float ms = -1.0f;
+  hipError_t e = hipSuccess;
+  if (which == 0) e = hipEventElapsedTime(&ms, h->ev_begin, h->ev_end);
+  else if (which == 1) e = hipEventElapsedTime(&ms, h->ev_c0, h->ev_c1);
+  else if (which == 2) e = hipEventElapsedTime(&ms, h->ev_e0, h->ev_e1);
+  else if (which == 3) { if (!h->tr_valid) return 0.0; e = hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1); }
+  else return -1.0;
+  return e == hipSuccess ? (double)ms : -1.0;
+}
+
+// ======================================================================== BGC_SourceSink ==
+
+extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (!a->tracers || !a->temp || !a->salt || !a->zmid || !a->dz || !a->zbot || !a->lat || !a->kmax || !a->fesedflux ||
+      !a->dust_flux_in || !a->sw_flux || !a->tend || !a->ph_prev || !a->ph_prev_alt)
+    return fail(h, OBGC_ERR_INVALID, "obgc_bgc_source_sink: null array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(a->grid);
+  if (v.ncol == 0) return OBGC_OK;
+  h->arena_used = 0;
+  h->timed_valid = false;
+  h->tr_valid = false;
+
+  // ---- stage caller arrays (no-op for device memory) ----
+  Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
+  const size_t kc1 = span_kc(v, 1);
+  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_BGC_NTRACER), true, false);
+  const int i_T = st.add(a->temp, kc1, true, false), i_S = st.add(a->salt, kc1, true, false);
+  const int i_zm = st.add(a->zmid, kc1, true, false), i_dz = st.add(a->dz, kc1, true, false);
+  const int i_zb = st.add(a->zbot, kc1, true, false), i_fs = st.add(a->fesedflux, kc1, true, false);
+  const int i_lat = st.add(a->lat, v.ncol * sizeof(double), true, false);
+  const int i_km = st.add(a->kmax, v.ncol * sizeof(int), true, false);
+  const int i_du = st.add(a->dust_flux_in, v.ncol * sizeof(double), true, false);
+  const int i_sw = st.add(a->sw_flux, v.ncol * sizeof(double), true, false);
+  // the host path copies whole strided spans back, so outputs with gaps (ld > extent) are read in first
+  const bool gaps = st.host && ((v.kfast ? v.sc != v.nlev : v.sk != v.ncol) || v.plane != (v.kfast ? v.sc * v.ncol : v.sk * v.nlev));
+  const int i_td = st.add(a->tend, span_kc(v, OBGC_BGC_NTRACER), gaps, true);
+  const int i_pp = st.add(a->ph_prev, kc1, true, true), i_pa = st.add(a->ph_prev_alt, kc1, true, true);
+  obgc_bgc_diag dd;
+  std::memset(&dd, 0, sizeof dd);
+  std::vector<std::pair<double**, int>> dslots;
+  if (a->diag) {
+    const obgc_bgc_diag& D = *a->diag;
+    const bool gaps_c = st.host && v.ldc != v.ncol;
+#define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, kc1, true, true)});
+    OBGC_BGC_DIAG_KC(X)
+#undef X
+#define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, span_kc(v, 4), gaps, true)});
+    OBGC_BGC_DIAG_KCA(X)
+#undef X
+#define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, span_c(v, 4), gaps_c, true)});
+    OBGC_BGC_DIAG_CA(X)
+#undef X
+#define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, v.ncol * sizeof(double), false, true)});
+    OBGC_BGC_DIAG_C(X)
+#undef X
+  }
+  // scratch for the saturation-horizon scan when the caller did not ask for those profiles
+  const bool want_zsat = a->diag && (a->diag->zsatcalc || a->diag->zsatarag);
+  size_t scratch = 0;
+  if (want_zsat) {
+    if (!a->diag->CO3) scratch += align_up(kc1);
+    if (!a->diag->co3_sat_calc) scratch += align_up(kc1);
+    if (!a->diag->co3_sat_arag) scratch += align_up(kc1);
+  }
+  int rc = arena_reserve(h, (st.host ? st.need : 0) + scratch);
+  if (rc != OBGC_OK) return rc;
+  rc = stage_in(h, st);
+  if (rc != OBGC_OK) return rc;
+  for (auto& s : dslots) *s.first = st.dev<double>(s.second);
+
+  BgcKernelArgs K;
+  std::memset(&K, 0, sizeof K);
+  K.g = v;
+  K.tracers = st.dev<const double>(i_tr);
+  K.temp = st.dev<const double>(i_T); K.salt = st.dev<const double>(i_S); K.zmid = st.dev<const double>(i_zm);
+  K.dz = st.dev<const double>(i_dz); K.zbot = st.dev<const double>(i_zb); K.fesed = st.dev<const double>(i_fs);
+  K.lat = st.dev<const double>(i_lat); K.kmax = st.dev<const int>(i_km); K.dust = st.dev<const double>(i_du);
+  K.sw = st.dev<const double>(i_sw);
+  K.tend = st.dev<double>(i_td); K.ph_prev = st.dev<double>(i_pp); K.ph_prev_alt = st.dev<double>(i_pa);
+  K.diag = dd;
+  K.have_diag = a->diag ? 1 : 0;
+  K.alt_co2_use_eco = a->alt_co2_use_eco;
+  if (want_zsat) {
+    auto carve = [&](double* have) -> double* {
+      if (have) return have;
+      double* p = (double*)(h->arena + h->arena_used);
+      h->arena_used += align_up(kc1);
+      return p;
+    };
+    K.co3_out = carve(dd.CO3);
+    K.sat_calc_out = carve(dd.co3_sat_calc);
+    K.sat_arag_out = carve(dd.co3_sat_arag);
+  }
+
+  // ---- launch: carbonate cells on s_aux beside the column sweep on s_main ----
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_begin, 0));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
+  launch_bgc_carbonate(K, h->bgc, h->s_aux);
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+  if (want_zsat) launch_bgc_zsat(K, h->s_aux);
+  HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  launch_bgc_ecosys(K, h->bgc, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+
+  rc = stage_out(h, st);
+  if (rc != OBGC_OK) return rc;
+  return finish(h, st.host);
+}
+
+// ===================================================================== BGC_SurfaceFluxes ==
+
+extern "C" int obgc_bgc_surface_fluxes(obgc_handle* h, const obgc_bgc_surface_fluxes_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (!a->tracers || !a->surfacePressure || !a->windSpeedSquared10m || !a->atmCO2 || !a->atmCO2_ALT_CO2 ||
+      !a->surfaceDepth || !a->SST || !a->SSS || !a->iceFraction || !a->surface_pH || !a->surface_pH_alt_co2 ||
+      !a->depositionFlux || !a->riverFlux || !a->gasFlux || !a->seaIceFlux || !a->netFlux)
+    return fail(h, OBGC_ERR_INVALID, "obgc_bgc_surface_fluxes: null array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(a->grid);
+  if (v.ncol == 0) return OBGC_OK;
+  h->arena_used = 0;
+  h->timed_valid = false;
+  Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
+  const size_t cb = v.ncol * sizeof(double), fb = span_c(v, OBGC_BGC_NTRACER);
+  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_BGC_NTRACER), true, false);
+  const int i_p = st.add(a->surfacePressure, cb, true, false), i_w = st.add(a->windSpeedSquared10m, cb, true, false);
+  const int i_c1 = st.add(a->atmCO2, cb, true, false), i_c2 = st.add(a->atmCO2_ALT_CO2, cb, true, false);
+  const int i_sd = st.add(a->surfaceDepth, cb, true, false), i_t = st.add(a->SST, cb, true, false);
+  const int i_s = st.add(a->SSS, cb, true, false), i_ice = st.add(a->iceFraction, cb, true, true);
+  const int i_ph = st.add(a->surface_pH, cb, true, true), i_pa = st.add(a->surface_pH_alt_co2, cb, true, true);
+  const int i_de = st.add(a->depositionFlux, fb, true, true), i_ri = st.add(a->riverFlux, fb, true, true);
+  const int i_ga = st.add(a->gasFlux, fb, true, true), i_si = st.add(a->seaIceFlux, fb, true, true);
+  const int i_ne = st.add(a->netFlux, fb, st.host && v.ldc != v.ncol, true);
+  obgc_bgc_flux_diag dd;
+  std::memset(&dd, 0, sizeof dd);
+  std::vector<std::pair<double**, int>> dslots;
+  if (a->diag) {
+#define X(n) if (a->diag->n) dslots.push_back({&dd.n, st.add(a->diag->n, cb, false, true)});
+    OBGC_BGC_FLUX_DIAG(X)
+#undef X
+  }
+  int rc = stage_in(h, st);
+  if (rc != OBGC_OK) return rc;
+  for (auto& s : dslots) *s.first = st.dev<double>(s.second);
+  SurfKernelArgs K;
+  std::memset(&K, 0, sizeof K);
+  K.g = v;
+  K.tracers = st.dev<const double>(i_tr);
+  K.surfacePressure = st.dev<const double>(i_p); K.wind2 = st.dev<const double>(i_w); K.atmCO2 = st.dev<const double>(i_c1);
+  K.atmCO2_alt = st.dev<const double>(i_c2); K.surfaceDepth = st.dev<const double>(i_sd); K.SST = st.dev<const double>(i_t);
+  K.SSS = st.dev<const double>(i_s); K.iceFraction = st.dev<double>(i_ice); K.surface_pH = st.dev<double>(i_ph);
+  K.surface_pH_alt = st.dev<double>(i_pa); K.depo = st.dev<double>(i_de); K.river = st.dev<double>(i_ri);
+  K.gas = st.dev<double>(i_ga); K.seaice = st.dev<double>(i_si); K.net = st.dev<double>(i_ne);
+  K.diag = dd;
+  K.have_diag = a->diag ? 1 : 0;
+  K.lcalc_o2 = a->lcalc_O2_gas_flux;
+  K.lcalc_co2 = a->lcalc_CO2_gas_flux;
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  launch_bgc_surface(K, h->bgc, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+  rc = stage_out(h, st);
+  if (rc != OBGC_OK) return rc;
+  return finish(h, st.host);
+}
+
+// =================================================================================== DMS ==
+
+extern "C" int obgc_dms_source_sink(obgc_handle* h, const obgc_dms_source_sink_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (!a->tracers || !a->dz || !a->kmax || !a->SST || !a->sw_flux || !a->tend)
+    return fail(h, OBGC_ERR_INVALID, "obgc_dms_source_sink: null array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(a->grid);
+  if (v.ncol == 0) return OBGC_OK;
+  h->arena_used = 0;
+  h->timed_valid = false;
+  Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
+  const size_t kc1 = span_kc(v, 1), cb = v.ncol * sizeof(double);
+  const bool gaps = st.host && ((v.kfast ? v.sc != v.nlev : v.sk != v.ncol) || v.plane != (v.kfast ? v.sc * v.ncol : v.sk * v.nlev));
+  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_DMS_NTRACER), true, false);
+  const int i_dz = st.add(a->dz, kc1, true, false), i_km = st.add(a->kmax, v.ncol * sizeof(int), true, false);
+  const int i_t = st.add(a->SST, cb, true, false), i_sw = st.add(a->sw_flux, cb, true, false);
+  const int i_td = st.add(a->tend, span_kc(v, OBGC_DMS_NTRACER), gaps, true);
+  obgc_dms_diag dd;
+  std::memset(&dd, 0, sizeof dd);
+  std::vector<std::pair<double**, int>> dslots;
+  if (a->diag) {
+#define X(n) if (a->diag->n) dslots.push_back({&dd.n, st.add(a->diag->n, kc1, true, true)});
+    OBGC_DMS_DIAG_KC(X)
+#undef X
+  }
+  int rc = stage_in(h, st);
+  if (rc != OBGC_OK) return rc;
+  for (auto& s : dslots) *s.first = st.dev<double>(s.second);
+  DmsKernelArgs K;
+  std::memset(&K, 0, sizeof K);
+  K.g = v;
+  K.tracers = st.dev<const double>(i_tr); K.dz = st.dev<const double>(i_dz); K.kmax = st.dev<const int>(i_km);
+  K.SST = st.dev<const double>(i_t); K.sw = st.dev<const double>(i_sw); K.tend = st.dev<double>(i_td);
+  K.diag = dd;
+  K.have_diag = a->diag ? 1 : 0;
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  launch_dms(K, h->dms, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+  rc = stage_out(h, st);
+  if (rc != OBGC_OK) return rc;
+  return finish(h, st.host);
+}
+
+extern "C" int obgc_dms_surface_fluxes(obgc_handle* h, const obgc_dms_surface_fluxes_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (!a->lcalc_DMS_gas_flux) return OBGC_OK;   // DMS_mod.F90:846
+  if (!a->tracers || !a->surfacePressure || !a->windSpeedSquared10m || !a->SST || !a->iceFraction || !a->netFlux)
+    return fail(h, OBGC_ERR_INVALID, "obgc_dms_surface_fluxes: null array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(a->grid);
+  if (v.ncol == 0) return OBGC_OK;
+  h->arena_used = 0;
+  h->timed_valid = false;
+  Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
+  const size_t cb = v.ncol * sizeof(double);
+  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_DMS_NTRACER), true, false);
+  const int i_p = st.add(a->surfacePressure, cb, true, false), i_w = st.add(a->windSpeedSquared10m, cb, true, false);
+  const int i_t = st.add(a->SST, cb, true, false), i_ice = st.add(a->iceFraction, cb, true, true);
+  const int i_ne = st.add(a->netFlux, span_c(v, OBGC_DMS_NTRACER), true, true);   // only two rows are written
+  obgc_dms_flux_diag dd;
+  std::memset(&dd, 0, sizeof dd);
+  std::vector<std::pair<double**, int>> dslots;
+  if (a->diag) {
+#define X(n) if (a->diag->n) dslots.push_back({&dd.n, st.add(a->diag->n, cb, false, true)});
+    OBGC_DMS_FLUX_DIAG(X)
+#undef X
+  }
+  int rc = stage_in(h, st);
+  if (rc != OBGC_OK) return rc;
+  for (auto& s : dslots) *s.first = st.dev<double>(s.second);
+  DmsSurfKernelArgs K;
+  std::memset(&K, 0, sizeof K);
+  K.g = v;
+  K.tracers = st.dev<const double>(i_tr); K.surfacePressure = st.dev<const double>(i_p); K.wind2 = st.dev<const double>(i_w);
+  K.SST = st.dev<const double>(i_t); K.iceFraction = st.dev<double>(i_ice); K.net = st.dev<double>(i_ne);
+  K.diag = dd;
+  K.have_diag = a->diag ? 1 : 0;
+  launch_dms_surface(K, h->dms, h->s_main);
+  HIP_TRY(h, hipGetLastError());
+  rc = stage_out(h, st);
+  if (rc != OBGC_OK) return rc;
+  return finish(h, st.host);
+}
+
+// ================================================================================ MACROS ==
+
+extern "C" int obgc_macros_source_sink(obgc_handle* h, const obgc_macros_source_sink_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (!a->tracers || !a->kmax || !a->tend) return fail(h, OBGC_ERR_INVALID, "obgc_macros_source_sink: null array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(a->grid);
+  if (v.ncol == 0) return OBGC_OK;
+  h->arena_used = 0;
+  h->timed_valid = false;
+  Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
+  const size_t kc1 = span_kc(v, 1);
+  const bool gaps = st.host && ((v.kfast ? v.sc != v.nlev : v.sk != v.ncol) || v.plane != (v.kfast ? v.sc * v.ncol : v.sk * v.nlev));
+  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_MACROS_NTRACER), true, false);
+  const int i_km = st.add(a->kmax, v.ncol * sizeof(int), true, false);
+  const int i_td = st.add(a->tend, span_kc(v, OBGC_MACROS_NTRACER), gaps, true);
+  obgc_macros_diag dd;
+  std::memset(&dd, 0, sizeof dd);
+  std::vector<std::pair<double**, int>> dslots;
+  if (a->diag) {
+#define X(n) if (a->diag->n) dslots.push_back({&dd.n, st.add(a->diag->n, kc1, true, true)});
+    OBGC_MACROS_DIAG_KC(X)
+#undef X
+  }
+  int rc = stage_in(h, st);
+  if (rc != OBGC_OK) return rc;
+  for (auto& s : dslots) *s.first = st.dev<double>(s.second);
+  MacrosKernelArgs K;
+  std::memset(&K, 0, sizeof K);
+  K.g = v;
+  K.tracers = st.dev<const double>(i_tr); K.kmax = st.dev<const int>(i_km); K.tend = st.dev<double>(i_td);
+  K.diag = dd;
+  K.have_diag = a->diag ? 1 : 0;
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  launch_macros(K, h->macros, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+  rc = stage_out(h, st);
+  if (rc != OBGC_OK) return rc;
+  return finish(h, st.host);
+}
+
+// ================================================================================= synth ==
+
+extern "C" int obgc_synth_fill(obgc_handle* h, const obgc_synth_args* a) {
+  if (!h || !a || a->nlev < 1 || a->ncol < 0) return OBGC_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  launch_synth(*a, a->ind, h->s_main);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->s_main));
+  return OBGC_OK;
+}

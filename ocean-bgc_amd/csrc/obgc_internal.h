@@ -1,0 +1,107 @@
+// Internal declarations shared by the HIP translation units of libobgc.
+// gfx950 (MI355X) only; fp64 throughout; no fast-math.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "obgc.h"
+
+namespace obgc {
+
+// Strided view of the level-dependent arrays of one call.  Element (k, c) of plane n
+// lives at  n*plane + k*sk + c*sc.   KFAST: sk = 1, sc = ld.   COLFAST: sk = ld, sc = 1.
+struct GridView {
+  int nlev, ncol;
+  long long sk, sc, plane, ldc;
+  int kfast;
+  __host__ __device__ inline long long at(int k, int c) const { return (long long)k * sk + (long long)c * sc; }
+};
+
+inline GridView make_view(const obgc_grid& g) {
+  GridView v;
+  v.nlev = g.nlev;
+  v.ncol = g.ncol;
+  v.kfast = (g.layout == OBGC_LAYOUT_KFAST);
+  long long ld = g.ld > 0 ? g.ld : (v.kfast ? g.nlev : g.ncol);
+  v.sk = v.kfast ? 1 : ld;
+  v.sc = v.kfast ? ld : 1;
+  v.plane = g.plane > 0 ? g.plane : (v.kfast ? ld * (long long)g.ncol : ld * (long long)g.nlev);
+  v.ldc = g.ldc > 0 ? g.ldc : g.ncol;
+  return v;
+}
+
+// ---------------------------------------------------------------- kernel arguments
+struct BgcKernelArgs {
+  GridView g;
+  const double* tracers;
+  const double *temp, *salt, *zmid, *dz, *zbot, *fesed;
+  const double *lat, *dust, *sw;
+  const int* kmax;
+  double* tend;
+  double *ph_prev, *ph_prev_alt;
+  // carbonate results needed by the saturation-horizon scan when the caller did not ask
+  // for the corresponding diagnostics (scratch owned by the handle, same shape as (k,c))
+  double *co3_out, *sat_calc_out, *sat_arag_out;
+  obgc_bgc_diag diag;
+  int have_diag;
+  int alt_co2_use_eco;
+};
+
+struct SurfKernelArgs {
+  GridView g;
+  const double* tracers;
+  const double *surfacePressure, *wind2, *atmCO2, *atmCO2_alt, *surfaceDepth, *SST, *SSS;
+  double *iceFraction, *surface_pH, *surface_pH_alt;
+  double *depo, *river, *gas, *seaice, *net;
+  obgc_bgc_flux_diag diag;
+  int have_diag;
+  int lcalc_o2, lcalc_co2;
+};
+
+struct DmsKernelArgs {
+  GridView g;
+  const double *tracers, *dz, *SST, *sw;
+  const int* kmax;
+  double* tend;
+  obgc_dms_diag diag;
+  int have_diag;
+};
+
+struct DmsSurfKernelArgs {
+  GridView g;
+  const double *tracers, *surfacePressure, *wind2, *SST;
+  double *iceFraction, *net;
+  obgc_dms_flux_diag diag;
+  int have_diag;
+};
+
+struct MacrosKernelArgs {
+  GridView g;
+  const double* tracers;
+  const int* kmax;
+  double* tend;
+  obgc_macros_diag diag;
+  int have_diag;
+};
+
+// ---------------------------------------------------------------- launchers (one per .hip file)
+void launch_bgc_carbonate(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_bgc_zsat(const BgcKernelArgs& a, hipStream_t s);
+void launch_bgc_ecosys(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_bgc_surface(const SurfKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
+void launch_dms_surface(const DmsSurfKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
+void launch_macros(const MacrosKernelArgs& a, const obgc_macros_params& p, hipStream_t s);
+void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s);
+// LDS-tiled transposes between the reference's KFAST order and the native COLFAST order
+// for `nplanes` planes: src/dst element strides as in GridView.
+void launch_transpose_k2c(const double* src, double* dst, int nlev, int ncol, long long src_ld,
+                          long long src_plane, long long dst_ld, long long dst_plane, int nplanes, hipStream_t s);
+void launch_transpose_c2k(const double* src, double* dst, int nlev, int ncol, long long src_ld,
+                          long long src_plane, long long dst_ld, long long dst_plane, int nplanes, hipStream_t s);
+
+// ---------------------------------------------------------------- small device helpers
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+
+}  // namespace obgc

@@ -1,0 +1,137 @@
+// On-device twin of ocean-bgc_amd/synth.py: deterministic synthetic columns in the native
+// COLFAST layout.  Only splitmix64 hashes and + - * / are used, and this file is built
+// with -ffp-contract=off, so every value is bit-identical to the numpy generator.
+// Workload utility for bench.py / tests, not part of the hot path.
+#include "obgc_internal.h"
+
+namespace obgc {
+
+namespace {
+
+constexpr unsigned long long SEED = 0x0B6C2026ull, CELL_SALT = 0x5DEECE66D1234567ull;
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(unsigned long long h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+__device__ __forceinline__ double ucol(unsigned long long c, int j) { return u01(splitmix64(SEED ^ (c * 64ull + (unsigned long long)j))); }
+__device__ __forceinline__ double ucell(unsigned long long c, unsigned long long k, int j) {
+  return u01(splitmix64(SEED ^ CELL_SALT ^ ((c * 256ull + k) * 64ull + (unsigned long long)j)));
+}
+
+struct SynthArgs {
+  obgc_synth_args a;
+  int ind[30];
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(const SynthArgs S) {
+  const obgc_synth_args& a = S.a;
+  const long long ncell = (long long)a.nlev * a.ncol;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncell) return;
+  const int cl = (int)(idx % a.ncol), k = (int)(idx / a.ncol);
+  const unsigned long long c = (unsigned long long)(a.col0 + cl);
+  const long long ix = (long long)k * a.ld + cl;
+  const int nz = a.nlev;
+  // grid
+  const double kf = (double)k;
+  const double dz = 1000.0 * (1.0 + 0.05 * kf);
+  const double zbot = 1000.0 * ((kf + 1.0) + 0.025 * (kf * (kf + 1.0)));
+  const double zmid = zbot - 0.5 * dz;
+  long long cm = (long long)c;
+  int kmax = nz - (int)(cm % 7);
+  if (kmax < 1) kmax = 1;
+  if (cm % 1000 == 999) kmax = 0;
+  if (cm % 1000 == 499) kmax = 1;
+  const double s = zmid / (zmid + 3.0e4);
+  const double q = 1.0 / (1.0 + zmid / 8.0e3);
+  const double e = q * q;
+  const double r = 1.0 / (1.0 + zmid / 4.0e4);
+  const double u1 = ucol(c, 1);
+  const double temp = -1.8 + (4.0 + 26.0 * (u1 * u1)) * r;
+  const double salt = 33.0 + 3.0 * ucol(c, 2);
+  if (a.dz) a.dz[ix] = dz;
+  if (a.zmid) a.zmid[ix] = zmid;
+  if (a.zbot) a.zbot[ix] = zbot;
+  if (a.temp) a.temp[ix] = temp;
+  if (a.salt) a.salt[ix] = salt;
+  if (a.fesedflux) a.fesedflux[ix] = (k == kmax - 1) ? 2.3e-6 * ucol(c, 14) : 0.0;
+  if (k == 0) {
+    if (a.kmax) a.kmax[cl] = kmax;
+    if (a.lat) a.lat[cl] = -90.0 + 180.0 * ucol(c, 0);
+    const double u3 = ucol(c, 3);
+    if (a.sw_flux) a.sw_flux[cl] = (u3 < 0.1) ? 20.0 * u3 : 300.0 * u3;
+    const double u4 = ucol(c, 4);
+    if (a.dust_flux_in) a.dust_flux_in[cl] = (u4 < 0.02) ? 0.0 : 1.0e-12 * (0.1 + u4);
+  }
+  if (!a.tracers) return;
+  double t[30];
+  // order = OBGC_BGC_TRACERS
+  t[0] = (0.3 + 2.0 * s) * (0.5 + ucol(c, 5));                       // po4
+  const double u6 = ucol(c, 6);
+  t[1] = (u6 < 0.01) ? 0.0 : (2.0 + 30.0 * s) * (0.5 + u6);          // no3
+  t[2] = (3.0 + 80.0 * s) * (0.5 + ucol(c, 7));                      // sio3
+  t[3] = (0.2 * e) * (0.5 + ucol(c, 8));                             // nh4
+  t[4] = (2.0e-4 + 7.0e-4 * s) * (0.5 + ucol(c, 9));                 // fe
+  const double u11 = ucol(c, 11);
+  const double o2f = (u11 < 0.02) ? 0.01 : ((u11 < 0.07) ? 0.12 : 1.0);
+  t[5] = ((250.0 - 220.0 * s) * (0.5 + ucol(c, 10))) * o2f;          // o2
+  const double u12 = ucol(c, 12);
+  t[6] = (2000.0 + 250.0 * s) * (0.95 + 0.1 * u12);                  // dic
+  t[7] = t[6] * (1.0 - 0.02 * ucol(c, 13));                          // dic_alt_co2
+  const double alkf = (ucol(c, 15) < 0.005) ? 0.8 : 1.0;
+  t[8] = ((2300.0 + 80.0 * s) * (0.95 + 0.1 * u12)) * alkf;          // alk
+  t[9] = (5.0 + 60.0 * e) * (0.5 + ucol(c, 16));                     // doc
+  t[10] = (0.5 + 4.0 * e) * (0.5 + ucol(c, 17));                     // don
+  t[11] = (1.0e-5 + 1.0e-4 * e) * (0.5 + ucol(c, 18));               // dofe
+  t[12] = (0.02 + 0.2 * e) * (0.5 + ucol(c, 19));                    // dop
+  t[13] = 0.03 * (0.5 + ucol(c, 20)) + 0.0 * s;                      // dopr
+  t[14] = 1.5 * (0.5 + ucol(c, 21)) + 0.0 * s;                       // donr
+  t[15] = (0.002 + 1.0 * e) * (0.5 + ucol(c, 22));                   // zooC
+  const double spC = (0.01 + 3.0 * e) * (0.5 + ucol(c, 23));
+  const double diatC = (0.01 + 2.5 * e) * (0.5 + ucol(c, 24));
+  const double diazC = (0.001 + 0.3 * e) * (0.5 + ucol(c, 25));
+  const double phaeoC = (0.005 + 1.0 * e) * (0.5 + ucol(c, 26));
+  double spChl = spC * (0.15 + 0.1 * ucol(c, 27));
+  double diatChl = diatC * (0.15 + 0.1 * ucol(c, 28));
+  double diazChl = diazC * (0.15 + 0.1 * ucol(c, 29));
+  double phaeoChl = phaeoC * (0.15 + 0.1 * ucol(c, 30));
+  const double u36 = ucol(c, 36);
+  const double car = (u36 < 0.03) ? 0.6 : 0.05 * (0.5 + u36);
+  // per-cell specials
+  const double h = ucell(c, (unsigned long long)k, 0);
+  const int hs = (int)((long long)(h * 400.0) % 4);
+  if (h < 0.01) {
+    if (hs == 0) spChl = 0.0;
+    if (hs == 1) diatChl = 0.0;
+    if (hs == 2) diazChl = 0.0;
+    if (hs == 3) phaeoChl = 0.0;
+  }
+  if (h >= 0.01 && h < 0.015) t[3] = -t[3];
+  if (h >= 0.015 && h < 0.02) t[4] = 0.0;
+  t[16] = spC; t[17] = spChl; t[18] = spC * (1.0e-5 + 3.0e-5 * ucol(c, 31)); t[19] = spC * car;
+  t[20] = diatC; t[21] = diatChl; t[22] = diatC * (1.0e-5 + 3.0e-5 * ucol(c, 32));
+  t[23] = diatC * (0.15 * (0.5 + ucol(c, 35)));
+  t[24] = phaeoC; t[25] = phaeoChl; t[26] = phaeoC * (1.0e-5 + 3.0e-5 * ucol(c, 34));
+  t[27] = diazC; t[28] = diazChl; t[29] = diazC * (1.0e-5 + 3.0e-5 * ucol(c, 33));
+#pragma unroll
+  for (int n = 0; n < 30; ++n) a.tracers[(long long)(S.ind[n] - 1) * a.plane + ix] = t[n];
+}
+
+}  // namespace
+
+void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s) {
+  SynthArgs S;
+  S.a = a;
+  if (S.a.ld <= 0) S.a.ld = a.ncol;
+  if (S.a.plane <= 0) S.a.plane = S.a.ld * a.nlev;
+  for (int i = 0; i < 30; ++i) S.ind[i] = ind30 ? ind30[i] : i + 1;
+  const long long ncell = (long long)a.nlev * a.ncol;
+  if (ncell <= 0) return;
+  hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, S);
+}
+
+}  // namespace obgc

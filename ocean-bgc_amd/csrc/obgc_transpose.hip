@@ -1,0 +1,64 @@
+// LDS-tiled transposition between the reference's level-fastest arrays X(k,column,n)
+// and the engine's column-fastest native order X[n][k][column].
+//
+// Pure data movement (16 B of traffic per element): both the global read and the global
+// write of a wavefront are contiguous rows; the 64 x 64 fp64 tile is staged in LDS with one
+// element of padding per row, so that the transposed ds_read_b64 of 32 lanes walks all 64
+// banks (row stride 65 doubles = 130 dwords -> bank advance of 2 per lane) without
+// conflicts.  One workgroup (256 lanes) per tile and plane.
+#include "obgc_internal.h"
+
+namespace obgc {
+
+namespace {
+
+constexpr int TILE = 64;
+
+// src(r, q) = src[r*src_ld + q]  ->  dst(q, r) = dst[q*dst_ld + r],  r < R, q < Q
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, int R,
+                                                        int Q, long long src_ld, long long dst_ld, long long src_plane,
+                                                        long long dst_plane) {
+  __shared__ double tile[TILE][TILE + 1];
+  const int q0 = blockIdx.x * TILE, r0 = blockIdx.y * TILE;
+  src += (long long)blockIdx.z * src_plane;
+  dst += (long long)blockIdx.z * dst_plane;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+#pragma unroll
+  for (int i = 0; i < TILE; i += 4) {
+    const int r = r0 + ty + i, q = q0 + tx;
+    if (r < R && q < Q) tile[ty + i][tx] = src[(long long)r * src_ld + q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TILE; i += 4) {
+    const int q = q0 + ty + i, r = r0 + tx;
+    if (r < R && q < Q) dst[(long long)q * dst_ld + r] = tile[tx][ty + i];
+  }
+}
+
+void launch(const double* src, double* dst, int R, int Q, long long src_ld, long long dst_ld, long long src_plane,
+            long long dst_plane, int nplanes, hipStream_t s) {
+  if (R <= 0 || Q <= 0 || nplanes <= 0) return;
+  // gridDim.y is limited to 65535 tiles = 4.19 M rows per launch
+  const int maxRows = 65535 * TILE;
+  for (int r0 = 0; r0 < R; r0 += maxRows) {
+    const int rr = (R - r0 < maxRows) ? (R - r0) : maxRows;
+    dim3 grid((Q + TILE - 1) / TILE, (rr + TILE - 1) / TILE, nplanes);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, src + (long long)r0 * src_ld, dst + r0, rr, Q, src_ld,
+                       dst_ld, src_plane, dst_plane);
+  }
+}
+
+}  // namespace
+
+void launch_transpose_k2c(const double* src, double* dst, int nlev, int ncol, long long src_ld, long long src_plane,
+                          long long dst_ld, long long dst_plane, int nplanes, hipStream_t s) {
+  launch(src, dst, ncol, nlev, src_ld, dst_ld, src_plane, dst_plane, nplanes, s);   // rows = columns, q = level
+}
+
+void launch_transpose_c2k(const double* src, double* dst, int nlev, int ncol, long long src_ld, long long src_plane,
+                          long long dst_ld, long long dst_plane, int nplanes, hipStream_t s) {
+  launch(src, dst, nlev, ncol, src_ld, dst_ld, src_plane, dst_plane, nplanes, s);   // rows = levels, q = column
+}
+
+}  // namespace obgc

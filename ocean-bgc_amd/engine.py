@@ -1,0 +1,222 @@
+"""Thin Python host over the C ABI (include/obgc.h).  Arrays may be numpy arrays (host
+memory) or torch tensors (device memory when `.is_cuda`); nothing is computed here."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class ObgcError(RuntimeError):
+    pass
+
+
+def _ptr(x):
+    """-> (address, is_device)"""
+    if x is None:
+        return None, None
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"] and not x.flags["F_CONTIGUOUS"]:
+            raise ObgcError("array must be contiguous")
+        return x.ctypes.data, False
+    if hasattr(x, "data_ptr"):      # torch tensor
+        return x.data_ptr(), bool(x.is_cuda)
+    raise ObgcError("unsupported array type %r" % type(x))
+
+
+def make_grid(nlev, ncol, layout, memspace, ld=0, plane=0, ldc=0):
+    g = L.Grid()
+    g.nlev, g.ncol, g.layout, g.memspace, g.ld, g.plane, g.ldc = nlev, ncol, layout, memspace, ld, plane, ldc
+    return g
+
+
+class Engine:
+    """One obgc_handle = one GPU + its streams and scratch (one per host thread per GPU)."""
+
+    def __init__(self, device=0, flags=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.obgc_create(C.byref(h), int(device), int(flags))
+        if rc != 0:
+            raise ObgcError("obgc_create(device=%d) failed: %s -- a gfx950 GPU is required, there is no CPU fallback"
+                            % (device, L.STATUS.get(rc, rc)))
+        self.h = h
+        self.bgc = L.BgcParams()
+        self.dms = L.DmsParams()
+        self.macros = L.MacrosParams()
+        self.lib.obgc_bgc_params_init(C.byref(self.bgc), None, 273.15)
+        self.lib.obgc_dms_params_init(C.byref(self.dms), None)
+        self.lib.obgc_macros_params_init(C.byref(self.macros), None)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.obgc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise ObgcError("%s: %s (%s)" % (what, L.STATUS.get(rc, rc), self.lib.obgc_last_error(self.h).decode()))
+
+    # ---- parameters ---------------------------------------------------------------------
+    def set_bgc_indices(self, ind30=None, T0_Kelvin=273.15):
+        arr = (C.c_int * 30)(*[int(i) for i in ind30]) if ind30 is not None else None
+        self.lib.obgc_bgc_params_init(C.byref(self.bgc), arr, float(T0_Kelvin))
+        self.push_params()
+
+    def set_dms_indices(self, ind14=None):
+        arr = (C.c_int * 14)(*[int(i) for i in ind14]) if ind14 is not None else None
+        self.lib.obgc_dms_params_init(C.byref(self.dms), arr)
+        self.push_params()
+
+    def set_macros_indices(self, ind8=None):
+        arr = (C.c_int * 8)(*[int(i) for i in ind8]) if ind8 is not None else None
+        self.lib.obgc_macros_params_init(C.byref(self.macros), arr)
+        self.push_params()
+
+    def push_params(self):
+        self._check(self.lib.obgc_set_bgc_params(self.h, C.byref(self.bgc)), "obgc_set_bgc_params")
+        self._check(self.lib.obgc_set_dms_params(self.h, C.byref(self.dms)), "obgc_set_dms_params")
+        self._check(self.lib.obgc_set_macros_params(self.h, C.byref(self.macros)), "obgc_set_macros_params")
+
+    def bgc_get_params(self):
+        """Same dictionary shape as the oracle bindings (for parameter-table tests)."""
+        areal = np.array([[getattr(self.bgc.autotrophs[a], n) for n in L.AUTOTROPH_REALS] for a in range(4)])
+        aint = np.array([[getattr(self.bgc.autotrophs[a], n) for n in L.AUTOTROPH_INTS] for a in range(4)], dtype=np.int32)
+        return dict(areal=areal, aint=aint, parms=np.array([getattr(self.bgc, n) for n in L.BGC_PARMS]),
+                    scalelen_z=np.array(self.bgc.parm_scalelen_z[:]), scalelen_vals=np.array(self.bgc.parm_scalelen_vals[:]))
+
+    def bgc_set_params(self, p):
+        for a in range(4):
+            for i, n in enumerate(L.AUTOTROPH_REALS):
+                setattr(self.bgc.autotrophs[a], n, float(p["areal"][a][i]))
+            for i, n in enumerate(L.AUTOTROPH_INTS):
+                setattr(self.bgc.autotrophs[a], n, int(p["aint"][a][i]))
+        for i, n in enumerate(L.BGC_PARMS):
+            setattr(self.bgc, n, float(p["parms"][i]))
+        for i in range(4):
+            self.bgc.parm_scalelen_z[i] = float(p["scalelen_z"][i])
+            self.bgc.parm_scalelen_vals[i] = float(p["scalelen_vals"][i])
+        self.push_params()
+
+    def sync(self):
+        self._check(self.lib.obgc_sync(self.h), "obgc_sync")
+
+    def last_kernel_ms(self, which=0):
+        return self.lib.obgc_last_kernel_ms(self.h, which)
+
+    # ---- helpers ------------------------------------------------------------------------
+    @staticmethod
+    def _fill(struct, names, arrays, memspace):
+        for nm in names:
+            a = arrays.get(nm) if isinstance(arrays, dict) else getattr(arrays, nm, None)
+            if a is None:
+                setattr(struct, nm, None)
+                continue
+            p, dev = _ptr(a)
+            if (L.OBGC_MEM_DEVICE if dev else L.OBGC_MEM_HOST) != memspace:
+                raise ObgcError("array %s is not in the call's memory space" % nm)
+            setattr(struct, nm, p)
+
+    @staticmethod
+    def _memspace(x):
+        _, dev = _ptr(x)
+        return L.OBGC_MEM_DEVICE if dev else L.OBGC_MEM_HOST
+
+    # ---- compute entry points -------------------------------------------------------------
+    def bgc_source_sink(self, nlev, ncol, layout, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesedflux,
+                        dust_flux_in, sw_flux, tend, ph_prev, ph_prev_alt, diag=None, alt_co2_use_eco=True, ld=0,
+                        plane=0, ldc=0):
+        ms = self._memspace(tracers)
+        a = L.BgcSourceSinkArgs()
+        a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        self._fill(a, ["tracers", "temp", "salt", "zmid", "dz", "zbot", "lat", "kmax", "fesedflux", "dust_flux_in",
+                       "sw_flux", "tend", "ph_prev", "ph_prev_alt"],
+                   dict(tracers=tracers, temp=temp, salt=salt, zmid=zmid, dz=dz, zbot=zbot, lat=lat, kmax=kmax,
+                        fesedflux=fesedflux, dust_flux_in=dust_flux_in, sw_flux=sw_flux, tend=tend, ph_prev=ph_prev,
+                        ph_prev_alt=ph_prev_alt), ms)
+        d = None
+        if diag is not None:
+            d = L.BgcDiag()
+            self._fill(d, L.BGC_DIAG_KC + L.BGC_DIAG_KCA + L.BGC_DIAG_CA + L.BGC_DIAG_C, diag, ms)
+            a.diag = C.pointer(d)
+        a.alt_co2_use_eco = 1 if alt_co2_use_eco else 0
+        self._check(self.lib.obgc_bgc_source_sink(self.h, C.byref(a)), "obgc_bgc_source_sink")
+
+    def bgc_surface_fluxes(self, nlev, ncol, layout, tracers, forcing, depositionFlux, riverFlux, gasFlux, seaIceFlux,
+                           netFlux, diag=None, lcalc_O2_gas_flux=True, lcalc_CO2_gas_flux=True, ld=0, plane=0, ldc=0):
+        ms = self._memspace(tracers)
+        a = L.BgcSurfaceFluxesArgs()
+        a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        arrs = dict(forcing)
+        arrs.update(tracers=tracers, depositionFlux=depositionFlux, riverFlux=riverFlux, gasFlux=gasFlux,
+                    seaIceFlux=seaIceFlux, netFlux=netFlux)
+        self._fill(a, ["tracers", "surfacePressure", "windSpeedSquared10m", "atmCO2", "atmCO2_ALT_CO2", "surfaceDepth",
+                       "SST", "SSS", "iceFraction", "surface_pH", "surface_pH_alt_co2", "depositionFlux", "riverFlux",
+                       "gasFlux", "seaIceFlux", "netFlux"], arrs, ms)
+        if diag is not None:
+            d = L.BgcFluxDiag()
+            self._fill(d, L.BGC_FLUX_DIAG, diag, ms)
+            a.diag = C.pointer(d)
+        a.lcalc_O2_gas_flux = 1 if lcalc_O2_gas_flux else 0
+        a.lcalc_CO2_gas_flux = 1 if lcalc_CO2_gas_flux else 0
+        self._check(self.lib.obgc_bgc_surface_fluxes(self.h, C.byref(a)), "obgc_bgc_surface_fluxes")
+
+    def dms_source_sink(self, nlev, ncol, layout, tracers, dz, kmax, SST, sw_flux, tend, diag=None, ld=0, plane=0, ldc=0):
+        ms = self._memspace(tracers)
+        a = L.DmsSourceSinkArgs()
+        a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        self._fill(a, ["tracers", "dz", "kmax", "SST", "sw_flux", "tend"],
+                   dict(tracers=tracers, dz=dz, kmax=kmax, SST=SST, sw_flux=sw_flux, tend=tend), ms)
+        if diag is not None:
+            d = L.DmsDiag()
+            self._fill(d, L.DMS_DIAG_KC, diag, ms)
+            a.diag = C.pointer(d)
+        self._check(self.lib.obgc_dms_source_sink(self.h, C.byref(a)), "obgc_dms_source_sink")
+
+    def dms_surface_fluxes(self, nlev, ncol, layout, tracers, forcing, netFlux, diag=None, lcalc_DMS_gas_flux=True, ld=0,
+                           plane=0, ldc=0):
+        ms = self._memspace(tracers)
+        a = L.DmsSurfaceFluxesArgs()
+        a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        arrs = dict(forcing)
+        arrs.update(tracers=tracers, netFlux=netFlux)
+        self._fill(a, ["tracers", "surfacePressure", "windSpeedSquared10m", "SST", "SSS", "iceFraction", "netFlux"], arrs, ms)
+        if diag is not None:
+            d = L.DmsFluxDiag()
+            self._fill(d, L.DMS_FLUX_DIAG, diag, ms)
+            a.diag = C.pointer(d)
+        a.lcalc_DMS_gas_flux = 1 if lcalc_DMS_gas_flux else 0
+        self._check(self.lib.obgc_dms_surface_fluxes(self.h, C.byref(a)), "obgc_dms_surface_fluxes")
+
+    def macros_source_sink(self, nlev, ncol, layout, tracers, kmax, tend, diag=None, ld=0, plane=0, ldc=0):
+        ms = self._memspace(tracers)
+        a = L.MacrosSourceSinkArgs()
+        a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        self._fill(a, ["tracers", "kmax", "tend"], dict(tracers=tracers, kmax=kmax, tend=tend), ms)
+        if diag is not None:
+            d = L.MacrosDiag()
+            self._fill(d, L.MACROS_DIAG_KC, diag, ms)
+            a.diag = C.pointer(d)
+        self._check(self.lib.obgc_macros_source_sink(self.h, C.byref(a)), "obgc_macros_source_sink")
+
+    def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, **dev_arrays):
+        """Fill device tensors (native COLFAST layout) with the synthetic workload."""
+        a = L.SynthArgs()
+        a.nlev, a.ncol, a.col0, a.ld, a.plane, a.ldc = nlev, ncol, col0, ld, plane, 0
+        keep = (C.c_int * 30)(*[int(i) for i in ind]) if ind is not None else None
+        a.ind = keep
+        for nm in ("tracers", "temp", "salt", "zmid", "dz", "zbot", "fesedflux", "lat", "dust_flux_in", "sw_flux", "kmax"):
+            x = dev_arrays.get(nm)
+            if x is None:
+                continue
+            p, dev = _ptr(x)
+            if not dev:
+                raise ObgcError("synth_fill needs device tensors")
+            setattr(a, nm, p)
+        self._check(self.lib.obgc_synth_fill(self.h, C.byref(a)), "obgc_synth_fill")

@@ -1,0 +1,161 @@
+"""Python mirror of the reference's module API on top of the GPU engine.
+
+The reference's call surface is
+
+    BGC_parms_init / BGC_init / BGC_SourceSink / BGC_SurfaceFluxes      (BGC_mod.F90:106-110)
+    DMS_parms_init / DMS_init / DMS_SourceSink / DMS_SurfaceFluxes      (DMS_mod.F90:51-55)
+    MACROS_parms_init / MACROS_init / MACROS_SourceSink                 (MACROS_mod.F90:51-54)
+
+with derived-type arguments whose array components are Fortran X(k, column[, n]).  Here the
+same routines take numpy arrays in exactly that memory order -- C-order shape [n, ncol, nlev]
+-- and return result dictionaries shaped like the oracle bindings', so a parity test reads
+`engine.BGC_SourceSink(...)` against `oracle.bgc_source_sink(...)` line for line.
+
+`path` selects how the arrays reach the kernels (every path ends in the same HIP kernels):
+  "host"            host pointers, reference layout: staged H2D/D2H by the library
+  "device_kfast"    device pointers, reference layout
+  "device_colfast"  device pointers, native column-fastest layout (what bench.py times)
+"""
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine, ObgcError
+
+PATHS = ("host", "device_kfast", "device_colfast")
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise ObgcError("device paths need a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch
+
+
+class ColumnEngine:
+    def __init__(self, device=0, bgc_indices=None, dms_indices=None, macros_indices=None, T0_Kelvin=273.15, path="host"):
+        assert path in PATHS
+        self.path = path
+        self.device = device
+        self.eng = Engine(device)
+        # *_parms_init followed by *_init, as the host must call them
+        self.eng.set_bgc_indices(bgc_indices, T0_Kelvin)
+        self.eng.set_dms_indices(dms_indices)
+        self.eng.set_macros_indices(macros_indices)
+
+    # ---- parameter access in the oracle bindings' shape ----
+    def bgc_get_params(self):
+        return self.eng.bgc_get_params()
+
+    def bgc_set_params(self, p):
+        self.eng.bgc_set_params(p)
+
+    def dms_get_parms(self):
+        return np.array([getattr(self.eng.dms, n) for n in L.DMS_PARMS])
+
+    def macros_get_parms(self):
+        return np.array([getattr(self.eng.macros, n) for n in L.MACROS_PARMS])
+
+    def names(self, module):
+        n = {0: 30, 1: 14, 2: 8}[module]
+        return [tuple(self.eng.lib.obgc_tracer_name(module, i, w).decode() for w in range(3)) for i in range(1, n + 1)]
+
+    # ---- array plumbing ----
+    def _up(self, x, kind):
+        """host reference-layout array -> what the selected path hands to the C ABI.
+        kind: 'kc' [.., ncol, nlev]; 'c' per-column / (column,n) arrays."""
+        x = np.ascontiguousarray(x)
+        if self.path == "host":
+            return x.copy()
+        torch = _torch()
+        t = torch.from_numpy(x).to("cuda:%d" % self.device)
+        if self.path == "device_colfast" and kind == "kc":
+            t = t.transpose(-1, -2).contiguous()      # [.., nlev, ncol]
+        return t
+
+    def _down(self, t, kind):
+        if isinstance(t, np.ndarray):
+            return t
+        if self.path == "device_colfast" and kind == "kc":
+            t = t.transpose(-1, -2).contiguous()
+        return t.cpu().numpy()
+
+    @property
+    def _layout(self):
+        return L.OBGC_LAYOUT_COLFAST if self.path == "device_colfast" else L.OBGC_LAYOUT_KFAST
+
+    # ---- BGC_SourceSink (BGC_mod.F90:340) ----
+    def BGC_SourceSink(self, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesed, dust, sw, ph_prev, ph_prev_alt,
+                       alt_co2_use_eco=True, diag_init=0.0, diagnostics=True):
+        n, nc, nz = tracers.shape
+        up = self._up
+        tend = up(np.full((30, nc, nz), diag_init), "kc")
+        php, pha = up(ph_prev, "kc"), up(ph_prev_alt, "kc")
+        diag = None
+        if diagnostics:
+            diag = {}
+            for nm in L.BGC_DIAG_KC:
+                diag[nm] = up(np.full((nc, nz), diag_init), "kc")
+            for nm in L.BGC_DIAG_KCA:
+                diag[nm] = up(np.full((4, nc, nz), diag_init), "kc")
+            for nm in L.BGC_DIAG_CA:
+                diag[nm] = up(np.full((4, nc), diag_init), "c")
+            for nm in L.BGC_DIAG_C:
+                diag[nm] = up(np.full((nc,), diag_init), "c")
+        self.eng.bgc_source_sink(nz, nc, self._layout, up(tracers, "kc"), up(temp, "kc"), up(salt, "kc"), up(zmid, "kc"),
+                                 up(dz, "kc"), up(zbot, "kc"), up(lat, "c"), up(np.asarray(kmax, dtype=np.int32), "c"),
+                                 up(fesed, "kc"), up(dust, "c"), up(sw, "c"), tend, php, pha, diag, alt_co2_use_eco)
+        out = dict(tend=self._down(tend, "kc"), ph_prev=self._down(php, "kc"), ph_prev_alt=self._down(pha, "kc"),
+                   kc={}, kca={}, ca={}, c={})
+        if diagnostics:
+            out["kc"] = {nm: self._down(diag[nm], "kc") for nm in L.BGC_DIAG_KC}
+            out["kca"] = {nm: self._down(diag[nm], "kc") for nm in L.BGC_DIAG_KCA}
+            out["ca"] = {nm: self._down(diag[nm], "c") for nm in L.BGC_DIAG_CA}
+            out["c"] = {nm: self._down(diag[nm], "c") for nm in L.BGC_DIAG_C}
+        return out
+
+    # ---- BGC_SurfaceFluxes (BGC_mod.F90:2706) ----
+    def BGC_SurfaceFluxes(self, tracers, forcing, depo, river, gas, seaice, net=None, lcalc_o2=True, lcalc_co2=True,
+                          diag_init=0.0):
+        n, nc, nz = tracers.shape
+        up = self._up
+        f = {nm: up(np.asarray(v, dtype=np.float64), "c") for nm, v in forcing.items()}
+        d, r, g, s = (up(x, "c") for x in (depo, river, gas, seaice))
+        netf = up(np.full((30, nc), diag_init) if net is None else net, "c")
+        fd = {nm: up(np.full((nc,), diag_init), "c") for nm in L.BGC_FLUX_DIAG}
+        self.eng.bgc_surface_fluxes(nz, nc, self._layout, up(tracers, "kc"), f, d, r, g, s, netf, fd, lcalc_o2, lcalc_co2)
+        dn = self._down
+        return dict(forcing={nm: dn(v, "c") for nm, v in f.items()}, depositionFlux=dn(d, "c"), riverFlux=dn(r, "c"),
+                    gasFlux=dn(g, "c"), seaIceFlux=dn(s, "c"), netFlux=dn(netf, "c"),
+                    fdiag={nm: dn(v, "c") for nm, v in fd.items()})
+
+    # ---- DMS (DMS_mod.F90:156, 778) ----
+    def DMS_SourceSink(self, tracers, dz, kmax, sst, sw, diag_init=0.0):
+        n, nc, nz = tracers.shape
+        up = self._up
+        tend = up(np.full((14, nc, nz), diag_init), "kc")
+        diag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.DMS_DIAG_KC}
+        self.eng.dms_source_sink(nz, nc, self._layout, up(tracers, "kc"), up(dz, "kc"),
+                                 up(np.asarray(kmax, dtype=np.int32), "c"), up(sst, "c"), up(sw, "c"), tend, diag)
+        return dict(tend=self._down(tend, "kc"), kc={nm: self._down(v, "kc") for nm, v in diag.items()})
+
+    def DMS_SurfaceFluxes(self, tracers, forcing, net=None, lcalc=True, diag_init=0.0):
+        n, nc, nz = tracers.shape
+        up = self._up
+        f = {nm: up(np.asarray(forcing[nm], dtype=np.float64), "c")
+             for nm in ("surfacePressure", "iceFraction", "windSpeedSquared10m", "SST", "SSS")}
+        netf = up(np.full((14, nc), diag_init) if net is None else net, "c")
+        fd = {nm: up(np.full((nc,), diag_init), "c") for nm in L.DMS_FLUX_DIAG}
+        self.eng.dms_surface_fluxes(nz, nc, self._layout, up(tracers, "kc"), f, netf, fd, lcalc)
+        dn = self._down
+        return dict(forcing={nm: dn(v, "c") for nm, v in f.items()}, netFlux=dn(netf, "c"),
+                    fdiag={nm: dn(v, "c") for nm, v in fd.items()})
+
+    # ---- MACROS (MACROS_mod.F90:137) ----
+    def MACROS_SourceSink(self, tracers, kmax, diag_init=0.0):
+        n, nc, nz = tracers.shape
+        up = self._up
+        tend = up(np.full((8, nc, nz), diag_init), "kc")
+        diag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.MACROS_DIAG_KC}
+        self.eng.macros_source_sink(nz, nc, self._layout, up(tracers, "kc"), up(np.asarray(kmax, dtype=np.int32), "c"),
+                                    tend, diag)
+        return dict(tend=self._down(tend, "kc"), kc={nm: self._down(v, "kc") for nm, v in diag.items()})

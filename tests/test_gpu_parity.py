@@ -1,0 +1,176 @@
+"""GPU parity tests (run with `-m gpu` on a real MI355X).  Every call goes through the
+C ABI of libobgc.so; the checker is the golden output of the unmodified reference
+(tests/golden) or the C oracle on the same seeded inputs.  Tolerances: tests/parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import parity as P
+from conftest import has_gpu
+from oracle import fields as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PATHS = ("device_colfast", "device_kfast", "host")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+@pytest.fixture(scope="module")
+def engines(pkg):
+    if not has_gpu():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False (no CPU fallback exists)")
+    from ocean_bgc_amd.modules import ColumnEngine
+    return {p: ColumnEngine(0, path=p) for p in PATHS}
+
+
+def _assert(rep, what):
+    assert rep.ok(), what + ":\n  " + "\n  ".join(rep.fail[:12])
+
+
+def bgc_common(g):
+    return (g["in.temp"], g["in.salt"], g["in.zmid"], g["in.dz"], g["in.zbot"], g["in.lat"], g["in.kmax"],
+            g["in.fesed"], g["in.dust"], g["in.sw"])
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_100"])
+def test_bgc_source_sink_vs_reference_golden(engines, path, fixture):
+    E = engines[path]
+    g = load(fixture)
+    nc, nz = g["in.temp"].shape
+    z = np.zeros((nc, nz))
+    a = E.BGC_SourceSink(g["in.bgc_tracers"], *bgc_common(g), z, z, alt_co2_use_eco=True, diag_init=-7.0)
+    _assert(P.compare_bgc(a, P.golden_bgc(g, "bgc_cold")), "%s cold %s" % (fixture, path))
+    for nm in F.BGC_DIAG_KC_UNTOUCHED:
+        assert (a["kc"][nm] == -7.0).all(), nm
+    # cells below the sea floor: tendencies and diagnostics are zero, PH_PREV untouched (quirk 11)
+    km = g["in.kmax"]
+    below = np.arange(nz)[None, :] >= km[:, None]
+    assert (a["tend"][:, below] == 0).all()
+    assert (a["ph_prev"][below] == 0).all()
+    # warm call: feed the REFERENCE's previous pH so both sides start from the same bracket
+    b = E.BGC_SourceSink(g["in.bgc_tracers_warm"], *bgc_common(g), g["bgc_cold.ph_prev"],
+                         g["bgc_cold.ph_prev_alt"] + 0.01 * (g["bgc_cold.ph_prev_alt"] != 0), alt_co2_use_eco=False,
+                         diag_init=-7.0)
+    _assert(P.compare_bgc(b, P.golden_bgc(g, "bgc_warm")), "%s warm %s" % (fixture, path))
+    assert (b["tend"][7] == 0.0).all()                      # alt_co2_use_eco = .false.
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_bgc_surface_fluxes_vs_reference_golden(engines, path):
+    E = engines[path]
+    g = load("branch_cols_60")
+    f = {nm: g["in.forcing." + nm] for nm in F.BGC_SURF_FORCING}
+    flux = [g["in." + nm] for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")]
+    s1 = E.BGC_SurfaceFluxes(g["in.bgc_tracers"], f, *flux, diag_init=-7.0)
+
+    def gold(pre):
+        return dict(forcing={nm: g["%s.forcing.%s" % (pre, nm)] for nm in F.BGC_SURF_FORCING},
+                    depositionFlux=g[pre + ".depositionFlux"], riverFlux=g[pre + ".riverFlux"], gasFlux=g[pre + ".gasFlux"],
+                    seaIceFlux=g[pre + ".seaIceFlux"], netFlux=g[pre + ".netFlux"],
+                    fdiag={nm: g["%s.fdiag.%s" % (pre, nm)] for nm in F.BGC_FLUX_DIAG})
+
+    _assert(P.compare_surface(s1, gold("surf_cold")), "surface cold " + path)
+    w = gold("surf_cold")
+    s2 = E.BGC_SurfaceFluxes(g["in.bgc_tracers_warm"], w["forcing"], w["depositionFlux"], w["riverFlux"], w["gasFlux"],
+                             w["seaIceFlux"], diag_init=-7.0)
+    _assert(P.compare_surface(s2, gold("surf_warm")), "surface warm " + path)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("fixture", ["branch_cols_60", "branch_cols_100"])
+def test_dms_macros_vs_reference_golden(engines, path, fixture):
+    E = engines[path]
+    g = load(fixture)
+    f = {nm: g["in.forcing." + nm] for nm in F.BGC_SURF_FORCING}
+    d = E.DMS_SourceSink(g["in.dms_tracers"], g["in.dz"], g["in.kmax"], f["SST"], g["in.sw"], diag_init=-7.0)
+    want = dict(tend=g["dms.tend"], kc={nm: g["dms.kc." + nm] for nm in F.DMS_DIAG_KC})
+    _assert(P.compare_simple(d, want, "dms"), "dms " + path)
+    ds = E.DMS_SurfaceFluxes(g["in.dms_tracers"], f, diag_init=-7.0)
+    rep = P.Report()
+    rep.note("diag", "dms.netFlux", P.e_norm(ds["netFlux"][:2], g["dms_surf.netFlux"][:2]), P.TOL_DIAG)
+    assert (ds["netFlux"][2:] == -7.0).all()                # only the dms / dmsp rows are written
+    for nm in F.DMS_FLUX_DIAG:
+        rep.note("diag", "dms.fdiag." + nm, P.e_norm(ds["fdiag"][nm], g["dms_surf.fdiag." + nm]), P.TOL_DIAG)
+    _assert(rep, "dms surface " + path)
+    m = E.MACROS_SourceSink(g["in.macros_tracers"], g["in.kmax"], diag_init=-7.0)
+    want = dict(tend=g["macros.tend"], kc={nm: g["macros.kc." + nm] for nm in F.MACROS_DIAG_KC})
+    _assert(P.compare_simple(m, want, "macros"), "macros " + path)
+
+
+def test_batch_vs_oracle_all_modules(engines, oracle, synth):
+    """20k seeded columns through the native path against the C oracle; permutation of tracer slots."""
+    E = engines["device_colfast"]
+    nc, nz = 20000, 60
+    syn = synth.generate(nc, nz, col0=31337)
+    tr = synth.bgc_tracer_array(syn)
+    args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"],
+            syn["dust"], syn["sw"])
+    z = np.zeros((nc, nz))
+    want = oracle.bgc_source_sink(*args, z, z)
+    got = E.BGC_SourceSink(*args, z, z)
+    rep = P.compare_bgc(got, want)
+    _assert(rep, "20k batch")
+    print("parity summary", rep.summary())
+    # tendencies-only mode must give the same tendencies and pH state bit for bit
+    lean = E.BGC_SourceSink(*args, z, z, diagnostics=False)
+    assert np.array_equal(lean["tend"], got["tend"]) and np.array_equal(lean["ph_prev"], got["ph_prev"])
+    f = syn["forcing"]
+    dtr, mtr = synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)
+    _assert(P.compare_simple(E.DMS_SourceSink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"]),
+                             oracle.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"]), "dms"), "dms 20k")
+    _assert(P.compare_simple(E.MACROS_SourceSink(mtr, syn["kmax"]), oracle.macros_source_sink(mtr, syn["kmax"]), "macros"),
+            "macros 20k")
+    flux = [syn[nm] for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")]
+    _assert(P.compare_surface(E.BGC_SurfaceFluxes(tr, f, *flux), oracle.bgc_surface_fluxes(tr, f, *flux)), "surface 20k")
+
+
+def test_permuted_slots_and_parameters(pkg, synth):
+    from ocean_bgc_amd.modules import ColumnEngine
+    from oracle import orabind
+    rng = np.random.RandomState(11)
+    perm = rng.permutation(30) + 1
+    E = ColumnEngine(0, bgc_indices=perm, T0_Kelvin=273.16, path="device_colfast")
+    O = orabind.Oracle(bgc_indices=perm, T0_Kelvin=273.16)
+    p = O.bgc_get_params()
+    assert np.array_equal(p["aint"], E.bgc_get_params()["aint"])
+    p["parms"] = p["parms"] * (1.0 + 0.1 * rng.rand(p["parms"].size))
+    p["areal"] = p["areal"] * (1.0 + 0.05 * rng.rand(*p["areal"].shape))
+    O.bgc_set_params(p)
+    E.bgc_set_params(p)
+    nc, nz = 2000, 60
+    syn = synth.generate(nc, nz, col0=999)
+    indices = {nm: int(perm[i]) for i, nm in enumerate(F.BGC_TRACERS)}
+    tr = synth.bgc_tracer_array(syn, indices)
+    args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"],
+            syn["dust"], syn["sw"])
+    z = np.zeros((nc, nz))
+    _assert(P.compare_bgc(E.BGC_SourceSink(*args, z, z), O.bgc_source_sink(*args, z, z)), "permuted")
+
+
+def test_device_generator_is_bit_identical_to_numpy(pkg, synth):
+    import torch
+    from ocean_bgc_amd.engine import Engine
+    eng = Engine(0)
+    nc, nz, col0 = 5000, 60, 123456
+    dev = "cuda:0"
+    t = {nm: torch.empty((nz, nc), dtype=torch.float64, device=dev) for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesedflux")}
+    tr = torch.empty((30, nz, nc), dtype=torch.float64, device=dev)
+    c = {nm: torch.empty((nc,), dtype=torch.float64, device=dev) for nm in ("lat", "dust_flux_in", "sw_flux")}
+    km = torch.empty((nc,), dtype=torch.int32, device=dev)
+    eng.synth_fill(nz, nc, col0, tracers=tr, kmax=km, **t, **c)
+    syn = synth.generate(nc, nz, col0=col0)
+    assert np.array_equal(km.cpu().numpy(), syn["kmax"])
+    for nm, key in (("temp", "temp"), ("salt", "salt"), ("zmid", "zmid"), ("dz", "dz"), ("zbot", "zbot"), ("fesedflux", "fesed")):
+        assert np.array_equal(t[nm].cpu().numpy().T, syn[key]), nm
+    for nm, key in (("lat", "lat"), ("dust_flux_in", "dust"), ("sw_flux", "sw")):
+        assert np.array_equal(c[nm].cpu().numpy(), syn[key]), nm
+    ref = synth.bgc_tracer_array(syn)
+    got = tr.cpu().numpy().transpose(0, 2, 1)
+    for i, nm in enumerate(synth.BGC_TRACERS):
+        assert np.array_equal(got[i], ref[i]), nm

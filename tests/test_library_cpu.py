@@ -1,0 +1,122 @@
+"""CPU-only checks of the product side: the C-ABI library loads, exports every symbol
+include/obgc.h declares, refuses to run without a GPU (no fallback), and its host-side
+parameter / metadata tables equal the reference's (golden dump of BGC_parms_init,
+DMS_parms_init, MACROS_parms_init and the *_init name tables)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+from oracle import fields as F
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def L(pkg):
+    from ocean_bgc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "ocean-bgc_amd", "csrc")])
+    return _lib
+
+
+def test_header_symbols_are_exported(L):
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "obgc.h")).read()
+    declared = set(re.findall(r"\b(obgc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"obgc_handle"}
+    assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.obgc_abi_version() == 1
+
+
+def test_field_lists_agree_with_oracle_lists(L):
+    pairs = [(L.BGC_TRACERS, F.BGC_TRACERS), (L.BGC_DIAG_KC, F.BGC_DIAG_KC), (L.BGC_DIAG_KCA, F.BGC_DIAG_KCA),
+             (L.BGC_DIAG_CA, F.BGC_DIAG_CA), (L.BGC_DIAG_C, F.BGC_DIAG_C), (L.BGC_FLUX_DIAG, F.BGC_FLUX_DIAG),
+             (L.DMS_TRACERS, F.DMS_TRACERS), (L.DMS_DIAG_KC, F.DMS_DIAG_KC), (L.DMS_FLUX_DIAG, F.DMS_FLUX_DIAG),
+             (L.DMS_PARMS, F.DMS_PARMS), (L.MACROS_TRACERS, F.MACROS_TRACERS), (L.MACROS_DIAG_KC, F.MACROS_DIAG_KC),
+             (L.MACROS_PARMS, F.MACROS_PARMS), (L.BGC_PARMS, F.BGC_PARMS), (L.AUTOTROPH_INTS, F.AUTOTROPH_INTS),
+             (L.AUTOTROPH_REALS, F.AUTOTROPH_REALS)]
+    for a, b in pairs:
+        assert a == b
+    assert len(L.BGC_DIAG_KC) == 61 and len(L.BGC_DIAG_KCA) == 18 and len(L.BGC_DIAG_C) == 17
+
+
+def test_oracle_header_lists_agree_with_fields_py():
+    hdr = open(os.path.join(ROOT, "oracle", "obgc_oracle.h")).read()
+
+    def xl(macro):
+        m = re.search(r"#define\s+%s\(X\)(.*?)\n(?!\s+X)" % macro, hdr, re.S)
+        return re.findall(r"X\((\w+)\)", m.group(1))
+
+    assert xl("ORA_DIAG_KC_LIST") == F.BGC_DIAG_KC
+    assert xl("ORA_DIAG_KCA_LIST") == F.BGC_DIAG_KCA
+    assert xl("ORA_DIAG_C_LIST") == F.BGC_DIAG_C
+    assert xl("ORA_DMS_DIAG_KC_LIST") == F.DMS_DIAG_KC
+    assert xl("ORA_SURF_FORCING_LIST") == F.BGC_SURF_FORCING
+
+
+def test_parameter_tables_equal_reference_dump(L):
+    lib = L.load()
+    g = dict(np.load(os.path.join(GOLD, "params.npz")))
+    p = L.BgcParams()
+    lib.obgc_bgc_params_init(C.byref(p), None, 273.15)
+    areal = np.array([[getattr(p.autotrophs[a], n) for n in L.AUTOTROPH_REALS] for a in range(4)])
+    aint = np.array([[getattr(p.autotrophs[a], n) for n in L.AUTOTROPH_INTS] for a in range(4)])
+    assert np.array_equal(areal, g["areal"])
+    assert np.array_equal(aint, g["aint"])          # includes BGC_init's derived Chl/C/Fe/Si/CaCO3 slots
+    assert np.array_equal(np.array([getattr(p, n) for n in L.BGC_PARMS]), g["parms"])
+    assert np.array_equal(np.array(p.parm_scalelen_z[:]), g["scalelen_z"])
+    assert np.array_equal(np.array(p.parm_scalelen_vals[:]), g["scalelen_vals"])
+    d = L.DmsParams()
+    lib.obgc_dms_params_init(C.byref(d), None)
+    assert np.array_equal(np.array([getattr(d, n) for n in L.DMS_PARMS]), g["dms_parms"])
+    m = L.MacrosParams()
+    lib.obgc_macros_params_init(C.byref(m), None)
+    assert np.array_equal(np.array([getattr(m, n) for n in L.MACROS_PARMS]), g["macros_parms"])
+    # permuted slots flow into the derived autotroph indices
+    perm = (C.c_int * 30)(*range(30, 0, -1))
+    lib.obgc_bgc_params_init(C.byref(p), perm, 273.15)
+    assert p.autotrophs[0].C_ind == 31 - 17 and p.autotrophs[1].Si_ind == 31 - 24 and p.autotrophs[2].Si_ind == 0
+
+
+def test_tracer_metadata_equals_reference_init(L):
+    lib = L.load()
+    g = dict(np.load(os.path.join(GOLD, "params.npz")))
+    for module, key, n in ((0, "bgc_names", 30), (1, "dms_names", 14), (2, "macros_names", 8)):
+        for i in range(n):
+            for w in range(3):
+                got = lib.obgc_tracer_name(module, i + 1, w).decode()
+                assert got.strip() == str(g[key][i][w]).strip(), (module, i, w, got)
+    assert lib.obgc_tracer_name(0, 31, 0) is None
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback(L, pkg):
+    from ocean_bgc_amd.engine import Engine, ObgcError
+    with pytest.raises(ObgcError, match="no CPU fallback"):
+        Engine(0)
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.obgc_create(C.byref(h), 0, 0) == -2 and not h.value      # OBGC_ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under ocean-bgc_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("ocean-bgc_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp or "__pycache__" in dp:
+                continue
+            for fn in files:
+                if fn.endswith((".so", ".o", ".mod", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|oracle/|liboracle|libbgc_ref|obgc_oracle", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
