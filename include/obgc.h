@@ -29,6 +29,10 @@
  *    keeps no pointer after a call returns.  State carried between calls lives in the
  *    caller's arrays exactly as in the reference (PH_PREV_3D, PH_PREV_ALT_CO2_3D,
  *    surface_pH, surface_pH_alt_co2; BGC_parms.F90:151-152, 170-171).
+ *  - Stream ordering: the engine runs on its own non-blocking HIP streams.  With device
+ *    memory the caller must make sure the producers of the input arrays have completed
+ *    (e.g. hipDeviceSynchronize / an event wait) before a call, and must not touch the
+ *    arrays until the call has returned (synchronous handles) or obgc_sync has (OBGC_ASYNC).
  *  - one handle per host thread per GPU.  Calls are synchronous unless the handle was
  *    created with OBGC_ASYNC (then obgc_sync completes them).
  */

@@ -164,6 +164,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch-ROCm wheels bundle their own libamdhip64; importing torch first makes libobgc.so
+        # bind to that same runtime instead of pulling a second copy from /opt/rocm (two HIP
+        # runtimes in one process leave torch without devices).  A Fortran host has no torch.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libobgc.so not found at %s -- build it with `make -C ocean-bgc_amd/csrc` "
                            "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)

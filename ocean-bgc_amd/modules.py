@@ -70,6 +70,7 @@ class ColumnEngine:
         t = torch.from_numpy(x).to("cuda:%d" % self.device)
         if self.path == "device_colfast" and kind == "kc":
             t = t.transpose(-1, -2).contiguous()      # [.., nlev, ncol]
+        self._ready()
         return t
 
     def _down(self, t, kind):
@@ -78,6 +79,13 @@ class ColumnEngine:
         if self.path == "device_colfast" and kind == "kc":
             t = t.transpose(-1, -2).contiguous()
         return t.cpu().numpy()
+
+    def _ready(self):
+        """Device arrays are produced on torch's stream; the engine's streams are non-blocking and
+        do not order against it, so the producer must have finished before the C-ABI call
+        (include/obgc.h, "Stream ordering")."""
+        if self.path != "host":
+            _torch().cuda.synchronize()
 
     @property
     def _layout(self):
