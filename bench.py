@@ -276,8 +276,20 @@ def main():
         else:
             dom, t_dom, b_dom = "bgc_carbonate_kernel", t_car, BYTES_CARBONATE[dk]
         achieved = active_cells * b_dom / (t_dom * 1e-3) / 1e9
+        # HBM bytes per launch from rocprofv3 PMC passes of this kernel revision (tools/pmc_summary.py);
+        # null when the committed table belongs to another revision / workload
+        traffic = None
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            rev = open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip()
+            key = dom + ("<true>" if diag_on else "<false>") if dom == "bgc_ecosys_kernel" else dom
+            if tab.get("kernel_rev") == rev and not args.columns:
+                traffic = tab["runs"]["%s_%s" % (args.config, dk)][key]["total"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": active_cells * b_dom,
                     "algorithmic_bytes_per_cell": b_dom, "active_cells_per_launch": active_cells,
                     "avg_launch_ms": t_dom,
                     "other_kernel_ms": {"bgc_carbonate_kernel": t_car, "bgc_ecosys_kernel": t_eco, "call_device_ms": t_call},
