@@ -46,6 +46,24 @@ BYTES_DMS = {"none": 136, "full": 352}
 BYTES_MACROS = {"none": 88, "full": 136}
 
 
+def shard(rank, world, ncol_per_gpu):
+    """Static column-range partition: rank r owns global columns
+    [r*ncol, (r+1)*ncol).  Weak scaling: the per-GPU batch does not depend on `world`."""
+    return rank * ncol_per_gpu, ncol_per_gpu
+
+
+def reduce_results(dist, elapsed, updates, device):
+    """max-over-ranks of the wall time, sum-over-ranks of the work; no data-path collective."""
+    if dist is None:
+        return elapsed, float(updates)
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    u = torch.tensor([float(updates)], dtype=torch.float64, device=device)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
 def _cpu_worker(job):
     """Runs in a child process: reference arithmetic on one column slice; returns (updates, seconds)."""
     kind, col0, nc, nz, modules = job
@@ -153,7 +171,7 @@ def main():
     ncol, nz, modules = CONFIGS[args.config]
     if args.columns:
         ncol = args.columns
-    col0 = rank * ncol                               # static column-range partition
+    col0, ncol = shard(rank, world, ncol)
     diag_on = args.diag == "full"
     eng = Engine(local_rank)
     f64 = dict(dtype=torch.float64, device=dev)
@@ -256,15 +274,7 @@ def main():
             rezero()                      # keeps every timed step cold; 2 small memsets per 8 steps, inside the timing
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(updates_per_step)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        updates_all = float(tot.item())
-    else:
-        updates_all = float(updates_per_step)
+    elapsed, updates_all = reduce_results(dist, elapsed, updates_per_step, dev)
     value = updates_all * args.steps / elapsed
 
     if rank == 0:

@@ -1,0 +1,127 @@
+"""GPU tests at BASELINE.json's full sizes through size-independent properties:
+determinism, shard invariance (bit-identical per-column results for any batch offset), the
+reference's zero-fill of land / sub-floor cells, conservation of C, N, P, Si (the Jint_*
+integrals vanish to round-off), warm-start consistency of the pH solve, and a strided column
+sample checked against the oracle."""
+import numpy as np
+import pytest
+
+import parity as P
+from conftest import has_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    import torch
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    return torch, L, Engine(0)
+
+
+def make_batch(torch, L, eng, nz, nc, col0, diag):
+    f64 = dict(dtype=torch.float64, device="cuda")
+    b = dict(nz=nz, nc=nc)
+    b["tr"] = torch.empty((30, nz, nc), **f64)
+    b["kc"] = {nm: torch.empty((nz, nc), **f64) for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesedflux")}
+    b["cc"] = {nm: torch.empty((nc,), **f64) for nm in ("lat", "dust_flux_in", "sw_flux")}
+    b["kmax"] = torch.empty((nc,), dtype=torch.int32, device="cuda")
+    eng.synth_fill(nz, nc, col0, tracers=b["tr"], kmax=b["kmax"], **b["kc"], **b["cc"])
+    b["tend"] = torch.full((30, nz, nc), -7.0, **f64)
+    b["ph"] = torch.zeros((2, nz, nc), **f64)
+    b["diag"] = None
+    if diag:
+        d = {}
+        for nm in L.BGC_DIAG_KC:
+            d[nm] = torch.full((nz, nc), -7.0, **f64)
+        for nm in L.BGC_DIAG_KCA:
+            d[nm] = torch.full((4, nz, nc), -7.0, **f64)
+        for nm in L.BGC_DIAG_CA:
+            d[nm] = torch.full((4, nc), -7.0, **f64)
+        for nm in L.BGC_DIAG_C:
+            d[nm] = torch.full((nc,), -7.0, **f64)
+        b["diag"] = d
+    torch.cuda.synchronize()
+    return b
+
+
+def run(L, eng, b):
+    kc, cc = b["kc"], b["cc"]
+    eng.bgc_source_sink(b["nz"], b["nc"], L.OBGC_LAYOUT_COLFAST, b["tr"], kc["temp"], kc["salt"], kc["zmid"], kc["dz"],
+                        kc["zbot"], cc["lat"], b["kmax"], kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"], b["tend"],
+                        b["ph"][0], b["ph"][1], b["diag"], True)
+
+
+def test_cfg2_100k_x_60_properties(gpu, oracle, synth):
+    torch, L, eng = gpu
+    nz, nc = 60, 100_000
+    b = make_batch(torch, L, eng, nz, nc, 0, diag=True)
+    run(L, eng, b)
+    tend1, ph1 = b["tend"].clone(), b["ph"].clone()
+    assert torch.isfinite(tend1).all() and torch.isfinite(ph1).all()
+    # determinism: the same inputs give the same bits
+    b["ph"].zero_()
+    torch.cuda.synchronize()
+    run(L, eng, b)
+    assert torch.equal(b["tend"], tend1) and torch.equal(b["ph"], ph1)
+    # zero fill below the sea floor and on land (BGC_mod.F90:570, 625-727, 802)
+    k = torch.arange(nz, device="cuda")[:, None]
+    below = k >= b["kmax"][None, :]
+    assert (tend1[:, below] == 0).all() and (ph1[:, below] == 0).all()
+    for nm in ("photoC_TOT", "CO3", "POC_REMIN"):
+        assert (b["diag"][nm][below] == 0).all(), nm
+    assert (b["diag"]["photoC"][:, below] == 0).all()
+    for nm in L.BGC_DIAG_KC_UNTOUCHED:
+        assert (b["diag"][nm] == -7.0).all()
+    land = b["kmax"] == 0
+    assert land.any() and (b["diag"]["O2_ZMIN"][land] == 0).all() and (b["diag"]["zsatcalc"][land] == 0).all()
+    # conservation: vertical integrals of the C, N, P, Si budgets close to round-off
+    scale = float(b["diag"]["photoC_TOT_zint"].abs().max())
+    for nm, fac in (("Jint_Ctot", 1.0), ("Jint_Ntot", 0.137), ("Jint_Ptot", 0.00855), ("Jint_Sitot", 0.137)):
+        assert float(b["diag"][nm].abs().max()) <= 1e-10 * scale * fac, nm
+    # shard invariance: a 1024-column window generated and solved on its own is bit-identical
+    w0, wn = 40_000, 1024
+    s = make_batch(torch, L, eng, nz, wn, w0, diag=True)
+    run(L, eng, s)
+    assert torch.equal(s["tend"], tend1[:, :, w0:w0 + wn])
+    assert torch.equal(s["ph"], ph1[:, :, w0:w0 + wn])
+    for nm in ("Jint_Ctot", "zsatarag", "photoC_NO3_TOT_zint"):
+        assert torch.equal(s["diag"][nm], b["diag"][nm][w0:w0 + wn]), nm
+    assert torch.equal(s["diag"]["light_lim"], b["diag"]["light_lim"][:, :, w0:w0 + wn])
+    # warm start from the converged state reproduces the pH to solver accuracy
+    cold = ph1.clone()
+    run(L, eng, b)       # b["ph"] now holds the cold solution -> narrow bracket
+    live = ~below
+    assert float((b["ph"][0][live] - cold[0][live]).abs().max()) < 1e-7
+    # strided sample against the oracle (inputs are bit-identical to the numpy generator)
+    cols = np.arange(0, nc, 397)
+    tr_h = b["tr"][:, :, cols].cpu().numpy().transpose(0, 2, 1)
+    kc_h = {nm: v[:, cols].cpu().numpy().T for nm, v in b["kc"].items()}
+    cc_h = {nm: v[cols].cpu().numpy() for nm, v in b["cc"].items()}
+    z = np.zeros((cols.size, nz))
+    want = oracle.bgc_source_sink(tr_h, kc_h["temp"], kc_h["salt"], kc_h["zmid"], kc_h["dz"], kc_h["zbot"], cc_h["lat"],
+                                  b["kmax"][cols].cpu().numpy(), kc_h["fesedflux"], cc_h["dust_flux_in"], cc_h["sw_flux"], z, z,
+                                  diagnostics=False)
+    rep = P.Report()
+    P.compare_tend(rep, "tend", tend1[:, :, cols].cpu().numpy().transpose(0, 2, 1), want["tend"])
+    rep.note("ph", "ph_prev", P.e_norm(ph1[0][:, cols].cpu().numpy().T, want["ph_prev"]), P.TOL_PH)
+    assert rep.ok(), "\n".join(rep.fail[:8])
+
+
+def test_cfg3_1M_x_60_tendencies_only(gpu):
+    """1M columns: no diagnostics (62 GB of them would fit, but the property is size, not content)."""
+    torch, L, eng = gpu
+    nz, nc = 60, 1_000_000
+    b = make_batch(torch, L, eng, nz, nc, 0, diag=False)
+    run(L, eng, b)
+    assert torch.isfinite(b["tend"]).all()
+    k = torch.arange(nz, device="cuda")[:, None]
+    below = k >= b["kmax"][None, :]
+    assert (b["tend"][:, below] == 0).all()
+    w0, wn = 987_000, 640
+    s = make_batch(torch, L, eng, nz, wn, w0, diag=False)
+    run(L, eng, s)
+    assert torch.equal(s["tend"], b["tend"][:, :, w0:w0 + wn]) and torch.equal(s["ph"], b["ph"][:, :, w0:w0 + wn])
