@@ -91,11 +91,12 @@ def test_cfg2_100k_x_60_properties(gpu, oracle, synth):
     for nm in ("Jint_Ctot", "zsatarag", "photoC_NO3_TOT_zint"):
         assert torch.equal(s["diag"][nm], b["diag"][nm][w0:w0 + wn]), nm
     assert torch.equal(s["diag"]["light_lim"], b["diag"]["light_lim"][:, :, w0:w0 + wn])
-    # warm start from the converged state reproduces the pH to solver accuracy
+    # warm start from the converged state reproduces the pH to the reference solver's accuracy:
+    # xacc = 1e-10 on [H+] ~ 1e-8 (co2calc.F90:47-53, "3 significant figures") -> |dpH| <~ 4e-3
     cold = ph1.clone()
     run(L, eng, b)       # b["ph"] now holds the cold solution -> narrow bracket
     live = ~below
-    assert float((b["ph"][0][live] - cold[0][live]).abs().max()) < 1e-7
+    assert float((b["ph"][0][live] - cold[0][live]).abs().max()) < 5e-3
     # strided sample against the oracle (inputs are bit-identical to the numpy generator)
     cols = np.arange(0, nc, 397)
     tr_h = b["tr"][:, :, cols].cpu().numpy().transpose(0, 2, 1)
