@@ -41,7 +41,11 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, FMA counted as 2
 
 # algorithmic bytes per ACTIVE cell (split per kernel in DESIGN.md)
 BYTES_CARBONATE = {"none": 88, "full": 168}
-BYTES_ECOSYS = {"none": 472, "full": 1432}
+BYTES_ECOSYS = {"none": 472, "full": 1432}     # PAR scan + cell kernel + particle sweep together
+# the cell kernel alone: reads 27 tracers + T, dz, zmid, zbot + PAR_in, writes 19 final tendencies (+ 9 staged
+# ones and 21 hand-off scratch values that are engine-internal, not algorithmic); with diagnostics it also
+# writes the 72 per-autotroph and 21 of the (k,column) diagnostics and reads S and zbot(k-1)
+BYTES_CELL = {"none": (27 + 4 + 19) * 8, "full": (27 + 6 + 19 + 72 + 21) * 8}
 BYTES_DMS = {"none": 136, "full": 352}
 BYTES_MACROS = {"none": 88, "full": 136}
 
@@ -230,7 +234,7 @@ def main():
     per_cell = 30 + (2 if "dms" in modules else 0) + (3 if "macros" in modules else 0)
     updates_per_step = active_cells * per_cell
     CF = L.OBGC_LAYOUT_COLFAST
-    kms = {"carbonate": [], "ecosys": [], "call": []}
+    kms = {"carbonate": [], "ecosys": [], "call": [], "cell": []}
 
     def step(i, record):
         p = ph[i % nbuf]
@@ -238,7 +242,7 @@ def main():
                             kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"], tend, p[0], p[1], diag, True)
         if record:
             kms["call"].append(eng.last_kernel_ms(0)); kms["carbonate"].append(eng.last_kernel_ms(1))
-            kms["ecosys"].append(eng.last_kernel_ms(2))
+            kms["ecosys"].append(eng.last_kernel_ms(2)); kms["cell"].append(eng.last_kernel_ms(4))
         if "surf" in extra:
             e = extra["surf"]
             e["forcing"]["surface_pH"].zero_(); e["forcing"]["surface_pH_alt_co2"].zero_()
@@ -280,9 +284,10 @@ def main():
     if rank == 0:
         dk = args.diag
         mean = lambda v: float(np.mean(v)) if v else float("nan")
-        t_car, t_eco, t_call = mean(kms["carbonate"]), mean(kms["ecosys"]), mean(kms["call"])
-        if t_eco >= t_car:
-            dom, t_dom, b_dom = "bgc_ecosys_kernel", t_eco, BYTES_ECOSYS[dk]
+        t_car, t_eco, t_call, t_cell = mean(kms["carbonate"]), mean(kms["ecosys"]), mean(kms["call"]), mean(kms["cell"])
+        # dominant kernel = the longest single launch: the ecosystem cell kernel or the carbonate kernel
+        if t_cell >= t_car:
+            dom, t_dom, b_dom = "bgc_cell_kernel", t_cell, BYTES_CELL[dk]
         else:
             dom, t_dom, b_dom = "bgc_carbonate_kernel", t_car, BYTES_CARBONATE[dk]
         achieved = active_cells * b_dom / (t_dom * 1e-3) / 1e9
@@ -292,7 +297,7 @@ def main():
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             rev = open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip()
-            key = dom + ("<true>" if diag_on else "<false>") if dom == "bgc_ecosys_kernel" else dom
+            key = dom
             if tab.get("kernel_rev") == rev and not args.columns:
                 traffic = tab["runs"]["%s_%s" % (args.config, dk)][key]["total"]
         except Exception:
@@ -302,7 +307,8 @@ def main():
                     "algorithmic_bytes_per_launch": active_cells * b_dom,
                     "algorithmic_bytes_per_cell": b_dom, "active_cells_per_launch": active_cells,
                     "avg_launch_ms": t_dom,
-                    "other_kernel_ms": {"bgc_carbonate_kernel": t_car, "bgc_ecosys_kernel": t_eco, "call_device_ms": t_call},
+                    "other_kernel_ms": {"bgc_carbonate_kernel": t_car, "bgc_cell_kernel": t_cell,
+                                        "ecosystem_par+cell+sweep": t_eco, "call_device_ms": t_call},
                     "whole_call_GBps": active_cells * (BYTES_CARBONATE[dk] + BYTES_ECOSYS[dk]) / (t_call * 1e-3) / 1e9,
                     "note": "pointwise fp64 kinetics: the binding resource is fp64 VALU + software transcendentals, "
                             "not HBM (SURVEY.md 8d); see DESIGN.md"}

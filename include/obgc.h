@@ -162,7 +162,8 @@ int obgc_set_macros_params(obgc_handle *h, const obgc_macros_params *p);
 void *obgc_stream(obgc_handle *h);
 /* device time of the kernels of the last *_source_sink / *_surface_fluxes call in ms
  * (HIP events on the engine's own streams); `which`: 0 whole call, 1 carbonate
- * kernel, 2 ecosystem column-sweep kernel, 3 layout transposes */
+ * kernel, 2 the ecosystem kernels (PAR scan + cell kernel + particle sweep), 3 layout transposes,
+ * 4 the ecosystem cell kernel alone */
 double obgc_last_kernel_ms(obgc_handle *h, int which);
 
 /* --------------------------------------------------------- BGC_SourceSink */

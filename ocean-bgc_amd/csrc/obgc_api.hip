@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,8 +19,9 @@ struct obgc_handle {
   hipStream_t s_main = nullptr;   // column-sweep kernels, copies, transposes
   hipStream_t s_aux = nullptr;    // cell-parallel carbonate kernel runs beside the sweep
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
-             ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr;
-  bool timed_valid = false, tr_valid = false;
+             ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+  bool timed_valid = false, tr_valid = false, cell_valid = false;
+  int sched = 0;   // experiment knob OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel
   obgc_bgc_params bgc;
   obgc_dms_params dms;
   obgc_macros_params macros;
@@ -283,9 +285,10 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
     delete h;
     return OBGC_ERR_HIP;
   }
-  hipEvent_t* evs[] = {&h->ev_begin, &h->ev_end, &h->ev_c0, &h->ev_c1, &h->ev_e0, &h->ev_e1, &h->ev_t0, &h->ev_t1, &h->ev_aux_done};
+  hipEvent_t* evs[] = {&h->ev_begin, &h->ev_end, &h->ev_c0, &h->ev_c1, &h->ev_e0, &h->ev_e1, &h->ev_t0, &h->ev_t1, &h->ev_aux_done, &h->ev_k0, &h->ev_k1};
   for (auto e : evs)
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
+  if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
   obgc_bgc_params_init(&h->bgc, nullptr, 273.15);
   obgc_dms_params_init(&h->dms, nullptr);
   obgc_macros_params_init(&h->macros, nullptr);
@@ -299,7 +302,7 @@ extern "C" int obgc_destroy(obgc_handle* h) {
   (void)hipStreamSynchronize(h->s_main);
   (void)hipStreamSynchronize(h->s_aux);
   if (h->arena) (void)hipFree(h->arena);
-  hipEvent_t evs[] = {h->ev_begin, h->ev_end, h->ev_c0, h->ev_c1, h->ev_e0, h->ev_e1, h->ev_t0, h->ev_t1, h->ev_aux_done};
+  hipEvent_t evs[] = {h->ev_begin, h->ev_end, h->ev_c0, h->ev_c1, h->ev_e0, h->ev_e1, h->ev_t0, h->ev_t1, h->ev_aux_done, h->ev_k0, h->ev_k1};
   for (auto e : evs)
     if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(h->s_main);
@@ -351,6 +354,7 @@ extern "C" double obgc_last_kernel_ms(obgc_handle* h, int which) {
   else if (which == 1) e = hipEventElapsedTime(&ms, h->ev_c0, h->ev_c1);
   else if (which == 2) e = hipEventElapsedTime(&ms, h->ev_e0, h->ev_e1);
   else if (which == 3) { if (!h->tr_valid) return 0.0; e = hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1); }
+  else if (which == 4) { if (!h->cell_valid) return 0.0; e = hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1); }
   else return -1.0;
   return e == hipSuccess ? (double)ms : -1.0;
 }
@@ -369,6 +373,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   h->arena_used = 0;
   h->timed_valid = false;
   h->tr_valid = false;
+  h->cell_valid = false;
 
   // ---- stage caller arrays (no-op for device memory) ----
   Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
@@ -412,6 +417,17 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
     if (!a->diag->co3_sat_calc) scratch += align_up(kc1);
     if (!a->diag->co3_sat_arag) scratch += align_up(kc1);
   }
+  // hand-off scratch of the ecosystem kernels, in the caller's index space
+  const long long span1 = (long long)(span_kc(v, 1) / sizeof(double));
+  const long long splane = (span1 + 31) & ~31LL;
+  const int nslots = a->diag ? (int)S_NDIAG : (int)S_NBASE;
+  scratch += align_up((size_t)nslots * splane * sizeof(double));
+  const size_t zbytes = align_up((size_t)(3 * v.plane + span1) * sizeof(double));
+  int nz_fallback = 0;
+  if (a->diag) {
+    nz_fallback = (a->diag->photoC ? 0 : 1) + (a->diag->photoC_NO3 ? 0 : 1) + (a->diag->CaCO3_form ? 0 : 1) + (a->diag->bSi_form ? 0 : 1);
+    scratch += nz_fallback * zbytes;
+  }
   int rc = arena_reserve(h, (st.host ? st.need : 0) + scratch);
   if (rc != OBGC_OK) return rc;
   rc = stage_in(h, st);
@@ -442,16 +458,44 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
     K.sat_arag_out = carve(dd.co3_sat_arag);
   }
 
-  // ---- launch: carbonate cells on s_aux beside the column sweep on s_main ----
+  {
+    auto carve_bytes = [&](size_t bytes) -> double* {
+      double* p = (double*)(h->arena + h->arena_used);
+      h->arena_used += align_up(bytes);
+      return p;
+    };
+    K.scratch = carve_bytes((size_t)nslots * splane * sizeof(double));
+    K.splane = splane;
+    if (a->diag) {
+      K.z_photoC = dd.photoC ? dd.photoC : carve_bytes(zbytes);
+      K.z_photoC_NO3 = dd.photoC_NO3 ? dd.photoC_NO3 : carve_bytes(zbytes);
+      K.z_CaCO3_form = dd.CaCO3_form ? dd.CaCO3_form : carve_bytes(zbytes);
+      K.z_bSi_form = dd.bSi_form ? dd.bSi_form : carve_bytes(zbytes);
+    }
+  }
+
+  // ---- launch: carbonate cells on s_aux beside the ecosystem kernels on s_main ----
+  // s_main: attenuation -> PAR scan -> cell kernel -> particle sweep.
+  // s_aux : carbonate cells -> saturation-horizon scan, released when the cell kernel is done so that the
+  //         compute-bound carbonate wavefronts fill the SIMDs the latency-bound sweep (1.5 waves per SIMD at
+  //         100k columns) leaves idle, instead of competing with the bandwidth-bound cell kernel.
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
-  HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_begin, 0));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1);
+  h->cell_valid = true;
+  if (h->sched == 1) {
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
+  } else {
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_begin, 0));
+  }
   HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
   launch_bgc_carbonate(K, h->bgc, h->s_aux);
   HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+  if (h->sched != 1) HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));   // zint reads the cell kernel's profiles
   if (want_zsat) launch_bgc_zsat(K, h->s_aux);
+  launch_bgc_zint(K, h->bgc, h->s_aux);     // column integrals of the cell kernel's profiles (diagnostics only)
   HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
-  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
-  launch_bgc_ecosys(K, h->bgc, h->s_main);
+  launch_bgc_ecosys_sweep(K, h->bgc, h->s_main);
   HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
   HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));

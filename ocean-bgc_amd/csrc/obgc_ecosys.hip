@@ -1,24 +1,40 @@
-// Ecosystem source/sink terms + sinking-particle sweep of BGC_SourceSink: one lane per
-// column, levels visited top to bottom.
+// Ecosystem source/sink terms of BGC_SourceSink as four kernels:
 //
-// Behavioural contract = BGC_mod.F90:733-931 (clamps, zero-mask, quotas, light),
-// 1041-1529 (kinetics), 1531-1536 -> 2116-2699 (Armstrong ballast model, bottom cell),
-// 1545-1968 (tendencies, diagnostics, column integrals, O2 minimum) and 2006-2109
-// (particle initialisation).  The carbonate block 935-1032 is NOT here: it has no
-// vertical coupling and runs as its own cell-parallel kernel (obgc_carbonate.hip).
+//   bgc_att_kernel     1 lane / cell     attenuation exp(-KPARdz) of every level (pow + exp)
+//   bgc_parscan_kernel 1 lane / column   PAR entering every level: one multiply per level
+//   bgc_cell_kernel    1 lane / cell     every cell-local term: quotas, uptake, photoadaptation,
+//                                        grazing, mortality, DOM, the PRODUCTION terms and decay
+//                                        factors of the sinking particles, 19 final tendencies
+//   bgc_sweep_kernel   1 lane / column   the Armstrong ballast recurrence top to bottom, iron
+//                                        scavenging, sea-floor burial, and the 11 tendencies and
+//                                        the column integrals that depend on it
 //
-// What is carried down a column in registers: PAR leaving the level, ten particle
-// fluxes, the QA-dust POC deficit and the running column integrals.  The reference keeps
-// five 11-member structs and 21 (k,column[,4]) scratch arrays for the same purpose.
-// Tracer planes are addressed through the caller's strides, so with the native COLFAST
-// layout every load and store of a wavefront is one contiguous 512-byte row.
+// Behavioural contract = BGC_mod.F90:733-931 (clamps, zero-mask, quotas, light), 1041-1529
+// (kinetics), 1531-1536 -> 2116-2699 (particles), 1545-1968 (tendencies, diagnostics, column
+// integrals, O2 minimum), 2006-2109 (particle initialisation).  The carbonate block 935-1032
+// is a separate cell-parallel kernel (obgc_carbonate.hip).
+//
+// Why three: the reference walks each column sequentially, but only the particle fluxes, the
+// QA-dust deficit, PAR and the column integrals are really carried from level to level -- a few
+// dozen flops per cell.  The ~2 000 flops of kinetics per cell are level-independent once PAR
+// is known.  With one lane per column the 100k-column config offers 1 563 wavefronts for 1 024
+// SIMDs (measured round 1: 5.2 ms, latency bound at one 512-register wave per SIMD); with one
+// lane per cell it offers 94 000.  The price is a scratch hand-off between the cell kernel and
+// the sweep (22 doubles per cell, + 5 with diagnostics) in the same layout as the caller's
+// arrays, so a single index addresses everything.
+//
+// Arithmetic order is the reference's everywhere except three tendency sums that the hand-off
+// re-associates (Fe, SiO3, PO4: the per-autotroph terms are folded before the particle terms
+// are added) and P_iron production (Fe scavenging added last); the change is a few ulp of the
+// largest term, far inside the parity bar, and is listed in DESIGN.md.
 #include "obgc_internal.h"
 
 namespace obgc {
 
 namespace {
 
-constexpr int kBlock = 64;   // one wavefront per workgroup: 100k columns -> 1563 workgroups over 256 CUs
+constexpr int kBlockCol = 64;
+constexpr int kBlockCell = 128;
 
 // ---- compile-time constants of BGC_parms.F90 (values, not names, are the contract) ----
 constexpr double DPS = 1.0 / 86400.0;                   // 37-40
@@ -51,8 +67,6 @@ constexpr double CACO3_GAMMA = 0.30, CACO3_MASS = 100.09, CACO3_RHO = 0.05 * CAC
 constexpr double SIO2_GAMMA = 0.030, SIO2_MASS = 60.08, SIO2_RHO = 0.05 * SIO2_MASS / POC_MASS;
 constexpr double DUST_DISS = 20000.0, DUST_GAMMA = 0.97, DUST_MASS = 1.0e9, DUST_RHO = 0.05 * DUST_MASS / POC_MASS;
 
-struct Flux { double s, h; };   // soft / hard sub-class flux leaving a level
-
 __device__ __forceinline__ double sum4(const double (&v)[4]) { return ((v[0] + v[1]) + v[2]) + v[3]; }
 
 // Garcia & Gordon (1992) O2 saturation in mmol/m^3 (BGC_mod.F90:3012-3083)
@@ -63,287 +77,557 @@ __device__ __forceinline__ double o2sat(double SST, double SSS, double T0K) {
   return v / 0.0223916;
 }
 
-template <bool DIAG>
-__global__ __launch_bounds__(kBlock) void bgc_ecosys_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+// Masked, clamped autotroph pools of one cell (BGC_mod.F90:764-785, 826-844)
+struct Pools { double Chl[4], C[4], Fe[4], Si[4], Ca[4]; };
+
+__device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_autotroph* at, long long ix, bool want_ca, Pools& p) {
+  const long long pl = A.g.plane;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    p.Chl[a] = dmax(0.0, A.tracers[(long long)(at[a].Chl_ind - 1) * pl + ix]);
+    p.C[a] = dmax(0.0, A.tracers[(long long)(at[a].C_ind - 1) * pl + ix]);
+    p.Fe[a] = dmax(0.0, A.tracers[(long long)(at[a].Fe_ind - 1) * pl + ix]);
+    p.Si[a] = (at[a].Si_ind > 0) ? dmax(0.0, A.tracers[(long long)(at[a].Si_ind - 1) * pl + ix]) : 0.0;
+    p.Ca[a] = (want_ca && at[a].CaCO3_ind > 0) ? dmax(0.0, A.tracers[(long long)(at[a].CaCO3_ind - 1) * pl + ix]) : 0.0;
+    bool empty = p.Chl[a] == 0.0 || p.C[a] == 0.0 || p.Fe[a] == 0.0;
+    if (at[a].Si_ind > 0) empty = empty || p.Si[a] == 0.0;
+    if (empty) { p.Chl[a] = 0.0; p.C[a] = 0.0; p.Fe[a] = 0.0; p.Si[a] = 0.0; p.Ca[a] = 0.0; }
+  }
+}
+
+// Morel & Maritorena attenuation across one level (BGC_mod.F90:914-921)
+__device__ __forceinline__ double kpar_dz(const double (&Chl)[4], double dz) {
+  const double w1 = dmax(sum4(Chl), 0.02);
+  const double K = (w1 < 0.13224) ? 0.000919 * pow(w1, 0.3536) : 0.001131 * pow(w1, 0.4562);
+  return K * dz;
+}
+
+// ------------------------------------------------------------------------- light: attenuation + scan
+// Attenuation of PAR across each level is cell-local (one pow + one exp, BGC_mod.F90:914-923); only the
+// product down the column is sequential.  One lane per cell computes exp(-KPARdz); the scan kernel then
+// needs a single multiply per level.
+__global__ __launch_bounds__(256) void bgc_att_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
   const GridView& g = A.g;
-  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncell) return;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  if (k >= A.kmax[c]) return;
+  const long long ix = g.at(k, c);
+  Pools p;
+  load_pools(A, P.autotrophs, ix, false, p);
+  const double KPARdz = kpar_dz(p.Chl, A.dz[ix]);
+  A.scratch[(long long)S_KPARDZ * A.splane + ix] = KPARdz;
+  A.scratch[(long long)S_ATT * A.splane + ix] = exp(-KPARdz);
+}
+
+__global__ __launch_bounds__(kBlockCol) void bgc_parscan_kernel(const BgcKernelArgs A) {
+  const GridView& g = A.g;
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
   if (c >= g.ncol) return;
+  int kmax = A.kmax[c];
+  if (kmax > g.nlev) kmax = g.nlev;
+  if (kmax < 1) return;
+  const double* att = A.scratch + (long long)S_ATT * A.splane;
+  double* par_in = A.scratch + (long long)S_PARIN * A.splane;
+  double PAR = dmax(0.0, A.sw[c]) * F_QSW_PAR;                     // BGC_mod.F90:813-814
+  int k = 0;
+  for (; k + 8 <= kmax; k += 8) {                                  // 8 independent loads in flight per lane
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = att[g.at(k + j, c)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { par_in[g.at(k + j, c)] = PAR; PAR = PAR * a[j]; }   // PAR_out = PAR_in * exp(-KPARdz), 923
+  }
+  for (; k < kmax; ++k) { par_in[g.at(k, c)] = PAR; PAR = PAR * att[g.at(k, c)]; }
+}
+
+// ------------------------------------------------------------------------------- cell kernel
+// Register discipline: the zooplankton terms only need the grazing rates, which need nothing but the
+// carbon pools -- so a cheap pre-pass produces f_zoo_detr / zoo_loss first.  Every summation chain of the
+// reference that starts from a zooplankton term (DOP_prod, DOFe_prod, P_iron production ...) can then be
+// accumulated in its original order inside ONE rolled loop over the autotrophs, and only scalar
+// accumulators stay live across iterations (the fully unrolled form needed 293 registers).
+struct Pool1 { double Chl, C, Fe, Si, Ca; };
+
+// clamped, zero-masked pools of one autotroph (BGC_mod.F90:764-785, 826-844)
+__device__ __forceinline__ Pool1 load_pool(const BgcKernelArgs& A, const obgc_autotroph& t, long long ix) {
+  const long long pl = A.g.plane;
+  Pool1 p;
+  p.Chl = dmax(0.0, A.tracers[(long long)(t.Chl_ind - 1) * pl + ix]);
+  p.C = dmax(0.0, A.tracers[(long long)(t.C_ind - 1) * pl + ix]);
+  p.Fe = dmax(0.0, A.tracers[(long long)(t.Fe_ind - 1) * pl + ix]);
+  p.Si = (t.Si_ind > 0) ? dmax(0.0, A.tracers[(long long)(t.Si_ind - 1) * pl + ix]) : 0.0;
+  p.Ca = (t.CaCO3_ind > 0) ? dmax(0.0, A.tracers[(long long)(t.CaCO3_ind - 1) * pl + ix]) : 0.0;
+  bool empty = p.Chl == 0.0 || p.C == 0.0 || p.Fe == 0.0;
+  if (t.Si_ind > 0) empty = empty || p.Si == 0.0;
+  if (empty) { p.Chl = 0.0; p.C = 0.0; p.Fe = 0.0; p.Si = 0.0; p.Ca = 0.0; }
+  return p;
+}
+
+// uniform (scalar) index into a 4-element register array without making it addressable
+__device__ __forceinline__ double sel4(const double (&v)[4], int a) {
+  return a == 0 ? v[0] : (a == 1 ? v[1] : (a == 2 ? v[2] : v[3]));
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  const GridView& g = A.g;
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
+  if (idx >= ncell) return;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  const long long ix = g.at(k, c), pl = g.plane;
   const obgc_bgc_diag& D = A.diag;
   const obgc_autotroph* at = P.autotrophs;
+  int kmax = A.kmax[c];
+  if (kmax > g.nlev) kmax = g.nlev;
+
+#define TRC(slot) dmax(0.0, A.tracers[(long long)((slot)-1) * pl + ix])
+#define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
+#define SCR(s) A.scratch[(long long)(s) * A.splane + ix]
+#define ST_KC(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
+#define ST_KCA(name, a, v) do { if (DIAG && D.name) D.name[(long long)(a) * pl + ix] = (v); } while (0)
+
+  if (k >= kmax) {
+    // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727)
+#pragma unroll 6
+    for (int n = 0; n < OBGC_BGC_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
+    if (DIAG) {
+#define ZKC(n) if (D.n) D.n[ix] = 0.0;
+      ZKC(tot_Nfix) ZKC(O2_PRODUCTION) ZKC(O2_CONSUMPTION) ZKC(AOU) ZKC(PO4_RESTORE) ZKC(NO3_RESTORE) ZKC(SiO3_RESTORE)
+      ZKC(PAR_avg) ZKC(POC_FLUX_IN) ZKC(POC_PROD) ZKC(POC_REMIN) ZKC(CaCO3_FLUX_IN) ZKC(CaCO3_PROD) ZKC(CaCO3_REMIN)
+      ZKC(SiO2_FLUX_IN) ZKC(SiO2_PROD) ZKC(SiO2_REMIN) ZKC(dust_FLUX_IN) ZKC(dust_REMIN) ZKC(P_iron_FLUX_IN)
+      ZKC(P_iron_PROD) ZKC(P_iron_REMIN) ZKC(auto_graze_TOT) ZKC(zoo_loss) ZKC(photoC_TOT) ZKC(photoC_NO3_TOT)
+      ZKC(DOC_prod) ZKC(DOC_remin) ZKC(DON_prod) ZKC(DON_remin) ZKC(DOFe_prod) ZKC(DOFe_remin) ZKC(DOP_prod)
+      ZKC(DOP_remin) ZKC(Fe_scavenge) ZKC(Fe_scavenge_rate) ZKC(NITRIF) ZKC(DENITRIF) ZKC(calcToSed) ZKC(pocToSed)
+      ZKC(ponToSed) ZKC(popToSed) ZKC(bsiToSed) ZKC(dustToSed) ZKC(pfeToSed) ZKC(SedDenitrif) ZKC(OtherRemin)
+      ZKC(tot_CaCO3_form)
+#undef ZKC
+#define ZKCA(n) if (D.n) { D.n[ix] = 0.0; D.n[pl + ix] = 0.0; D.n[2 * pl + ix] = 0.0; D.n[3 * pl + ix] = 0.0; }
+      ZKCA(N_lim) ZKCA(P_lim) ZKCA(Fe_lim) ZKCA(SiO3_lim) ZKCA(light_lim) ZKCA(photoC) ZKCA(photoC_NO3) ZKCA(photoFe)
+      ZKCA(photoNO3) ZKCA(photoNH4) ZKCA(DOP_uptake) ZKCA(PO4_uptake) ZKCA(auto_graze) ZKCA(auto_loss) ZKCA(auto_agg)
+      ZKCA(bSi_form) ZKCA(CaCO3_form) ZKCA(Nfix)
+#undef ZKCA
+    }
+    return;
+  }
+
   const double T0K = P.T0_Kelvin_BGC;
+  const double lat = A.lat[c];
+  const bool north = lat >= 0.0, south_or_eq = lat <= 0.0;
+  const double T = A.temp[ix], dz = A.dz[ix], zc = A.zmid[ix], zb = A.zbot[ix];
+  // clamped local copies (747-762)
+  const double PO4 = TRC(P.ind[0]), NO3 = TRC(P.ind[1]), SiO3 = TRC(P.ind[2]), NH4 = TRC(P.ind[3]), Fe = TRC(P.ind[4]),
+               O2 = TRC(P.ind[5]), DOC = TRC(P.ind[9]), DON = TRC(P.ind[10]), DOFe = TRC(P.ind[11]), DOP = TRC(P.ind[12]),
+               DOPr = TRC(P.ind[13]), DONr = TRC(P.ind[14]), zooC = TRC(P.ind[15]);
+
+  // light (907-924): attenuation and PAR entering the level come from the att / scan kernels
+  const double PAR_in = SCR(S_PARIN);
+  const double KPARdz = SCR(S_KPARDZ);
+  const double att = SCR(S_ATT);
+  const double PAR_out = PAR_in * att;
+  const double PAR_avg = PAR_in * (1.0 - att) / KPARdz;
+
+  // temperature response and loss thresholds (1041-1055)
+  const double Tfunc = pow(Q_10, ((T + T0K) - (TREF + T0K)) / 10.0);
+  double f_loss_thres;
+  if (zc > THRES_Z1) f_loss_thres = (zc < THRES_Z2) ? (THRES_Z2 - zc) / (THRES_Z2 - THRES_Z1) : 0.0;
+  else f_loss_thres = 1.0;
+
+  // ---- pre-pass: Pprime (1072-1094), grazing (1297-1324), zooplankton losses (1395-1415) ----
+  double Pprime[4], graze[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const Pool1 p = load_pool(A, at[a], ix);
+    double C_loss_thres = f_loss_thres * at[a].loss_thres;
+    if (at[a].temp_function == TFNC_Q10) {
+      if (T < at[a].temp_thres) C_loss_thres = f_loss_thres * at[a].loss_thres2;
+    } else if (at[a].temp_function == TFNC_QUASI_MMRT) {
+      const double tmpTmax = north ? at[a].temp_thresN : at[a].temp_thresS;
+      if (T > tmpTmax) C_loss_thres = f_loss_thres * at[a].loss_thres2;
+    }
+    Pprime[a] = dmax(p.C - C_loss_thres, 0.0);
+  }
+  double w1 = 0.0, w2 = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    double cls = 0.0;   // carbon of the grazee class this autotroph belongs to
+#pragma unroll
+    for (int a2 = 0; a2 < 4; ++a2)
+      if (at[a2].grazee_ind == at[a].grazee_ind) cls = cls + Pprime[a2];
+    double z_umax = at[a].z_umax_0 * Tfunc;
+    if (a + 1 == P.diat_ind) {
+      if (north && (T > at[a].temp_optN))
+        z_umax = z_umax * dmax((at[a].temp_thresN - T) / (at[a].temp_thresN - at[a].temp_optN), 0.95);
+      else if (south_or_eq && (T > at[a].temp_optS))
+        z_umax = z_umax * dmax((at[a].temp_thresS - T) / (at[a].temp_thresS - at[a].temp_optS), 0.95);
+    }
+    graze[a] = (cls > 0.0) ? (Pprime[a] / cls) * z_umax * zooC * (cls / (cls + at[a].z_grz)) : 0.0;
+    w1 = w1 + at[a].f_zoo_detr * (graze[a] + EPSC * EPSTINV);
+    w2 = w2 + (graze[a] + EPSC * EPSTINV);
+  }
+  const double f_zoo_detr = w1 / w2;
+  const double Zprime = dmax(zooC - f_loss_thres * LOSS_THRES_ZOO, 0.0);
+  const double zoo_loss = (P.parm_z_mort2_0 * pow(Zprime, 1.5) + P.parm_z_mort_0 * Zprime) * Tfunc;
+  const double zoo_loss_doc = (1.0 - P.parm_labile_ratio) * (1.0 - f_zoo_detr) * zoo_loss;
+  const double zoo_loss_dic = P.parm_labile_ratio * (1.0 - f_zoo_detr) * zoo_loss;
+
+  // ---- autotroph kinetics (1107-1388): one rolled loop, scalar accumulators only ----
+  double DOP_prod = QP_ZOO_POM * zoo_loss_doc;                 // 1423-1430
+  double DOFe_prod = QFE_ZOO * zoo_loss_doc;                   // 1431-1434
+  double PfeLoc = (zoo_loss * f_zoo_detr * QFE_ZOO);           // 1524-1529 without the scavenging term
+  double sNO3V = 0, sNH4V = 0, sPO4V = 0, sDOPV = 0, sPhotoFe = 0, sPhotoC = 0, s_gr_zoo = 0, s_ls_doc = 0, s_gr_doc = 0,
+         s_ls_dic = 0, s_gr_dic = 0, s_gr_poc = 0, s_agg = 0, s_ls_poc = 0;
+  double L_fe_a = 0.0, L_po4_a = 0.0, L_sio3_a = 0.0, nexc = 0.0, ca_x = 0.0, ca_prod = 0.0, O2_PRODUCTION = 0.0;
+  double d_totCa = 0.0, d_totNfix = 0.0, d_pCNO3 = 0.0, prodCa = 0.0, prodSi = 0.0;
+  double sC = 0.0, sCa = 0.0, sSi = 0.0, sNfix = 0.0, sQpC = 0.0, chl = 0.0;   // diagnostics: integrand pieces
+#pragma unroll 1
+  for (int a = 0; a < 4; ++a) {
+    const obgc_autotroph& t = at[a];
+    const Pool1 p = load_pool(A, t, ix);
+    const double Pp = sel4(Pprime, a), gz = sel4(graze, a);
+    // quotas for growth (850-898)
+    const double Cden = p.C + EPSC;
+    const double thetaC = p.Chl / Cden;
+    const double Qfe = p.Fe / Cden;
+    const double Qsi = (t.Si_ind > 0) ? dmin(p.Si / Cden, GQSI_MAX) : 0.0;
+    double gQfe = t.gQfe_0;
+    if (Fe < CKS * t.kFe) gQfe = dmax((gQfe * Fe / (CKS * t.kFe)), t.gQfe_min);
+    double gQsi = 0.0;
+    if (t.Si_ind > 0) {
+      gQsi = GQSI_0;
+      if ((Fe < CKSI * t.kFe) && (Fe > 0.0) && (SiO3 > (CKSI * t.kSiO3))) gQsi = dmin((gQsi * CKSI * t.kFe / Fe), GQSI_MAX);
+      if (Fe == 0.0) gQsi = GQSI_MAX;
+      if (SiO3 < (CKSI * t.kSiO3)) gQsi = dmax((gQsi * SiO3 / (CKSI * t.kSiO3)), GQSI_MIN);
+    }
+    double QCa = 0.0;
+    if (t.CaCO3_ind > 0) {
+      QCa = p.Ca / Cden;
+      if (QCa > QCACO3_MAX) QCa = QCACO3_MAX;
+    }
+    // nutrient limitation (1108-1139)
+    const double rNO3 = NO3 / t.kNO3, rNH4 = NH4 / t.kNH4;
+    const double VNO3 = rNO3 / (1.0 + rNO3 + rNH4);
+    const double VNH4 = rNH4 / (1.0 + rNO3 + rNH4);
+    double VNtot = VNO3 + VNH4;
+    if (t.Nfixer) VNtot = 1.0;
+    ST_KCA(N_lim, a, VNtot);
+    const double VFe = Fe / (Fe + t.kFe);
+    ST_KCA(Fe_lim, a, VFe);
+    double f_nut = dmin(VNtot, VFe);
+    const double rPO4 = PO4 / t.kPO4, rDOP = DOP / t.kDOP;
+    const double VPO4 = rPO4 / (1.0 + rPO4 + rDOP);
+    const double VDOP = rDOP / (1.0 + rPO4 + rDOP);
+    const double VPtot = VPO4 + VDOP;
+    ST_KCA(P_lim, a, VPtot);
+    f_nut = dmin(f_nut, VPtot);
+    double VSiO3 = 0.0;
+    if (t.kSiO3 > 0.0) {
+      VSiO3 = SiO3 / (SiO3 + t.kSiO3);
+      f_nut = dmin(f_nut, VSiO3);
+    }
+    ST_KCA(SiO3_lim, a, VSiO3);
+    // photosynthesis (1146-1181)
+    double PCmax = t.PCref * f_nut * Tfunc;
+    if (T < t.temp_thres) PCmax = 0.0;
+    if (t.temp_function == TFNC_QUASI_MMRT) {
+      const double tmpTopt = north ? t.temp_optN : t.temp_optS;
+      const double tmpTmax = north ? t.temp_thresN : t.temp_thresS;
+      PCmax = PCmax * dmin(1.0, ((tmpTmax - T) / (tmpTmax - tmpTopt)));
+      if (T > tmpTmax) PCmax = 0.0;
+    }
+    const double light_lim = (1.0 - exp((-1.0 * t.alphaPI * thetaC * PAR_avg) / (PCmax + EPSTINV)));
+    const double PCphoto = PCmax * light_lim;
+    ST_KCA(light_lim, a, light_lim);
+    const double photoC = PCphoto * p.C;
+    double NO3_V, NH4_V, VNC, pC_NO3;
+    if (VNtot > 0.0) {
+      NO3_V = (VNO3 / VNtot) * photoC * QN;
+      NH4_V = (VNH4 / VNtot) * photoC * QN;
+      VNC = PCphoto * QN;
+      pC_NO3 = (VNO3 / VNtot) * photoC;            // 1828-1834
+    } else { NO3_V = 0.0; NH4_V = 0.0; VNC = 0.0; pC_NO3 = 0.0; }
+    ST_KCA(photoNO3, a, NO3_V);
+    ST_KCA(photoNH4, a, NH4_V);
+    double PO4_V, DOP_V;
+    if (VPtot > 0.0) {
+      PO4_V = (VPO4 / VPtot) * photoC * t.Qp;
+      DOP_V = (VDOP / VPtot) * photoC * t.Qp;
+    } else { PO4_V = 0.0; DOP_V = 0.0; }
+    ST_KCA(PO4_uptake, a, PO4_V);
+    ST_KCA(DOP_uptake, a, DOP_V);
+    const double photoFe = photoC * gQfe;
+    ST_KCA(photoFe, a, photoFe);
+    const double photoSi = (t.Si_ind > 0) ? photoC * gQsi : 0.0;
+    double wk = t.alphaPI * thetaC * PAR_avg;
+    double photoacc;
+    if (wk > 0.0) {
+      const double pChl = t.thetaN_max * PCphoto / wk;
+      photoacc = (pChl * VNC / thetaC) * p.Chl;
+    } else photoacc = 0.0;
+    double CaProd = 0.0;
+    if (t.imp_calcifier) {   // 1255-1278
+      double cp = P.parm_f_prod_sp_CaCO3 * photoC;
+      cp = cp * f_nut;
+      if (T < CACO3_TEMP_THRES1) cp = cp * dmax((T - CACO3_TEMP_THRES2), 0.0) / (CACO3_TEMP_THRES1 - CACO3_TEMP_THRES2);
+      if (p.C > CACO3_SP_THRES) cp = dmin((cp * p.C / CACO3_SP_THRES), (F_PHOTOSP_CACO3 * photoC));
+      CaProd = cp;
+      d_totCa = d_totCa + cp;
+    }
+    if (DIAG) {   // the sweep integrates these four profiles; caller's arrays or scratch
+      A.z_photoC[(long long)a * pl + ix] = photoC;
+      A.z_photoC_NO3[(long long)a * pl + ix] = pC_NO3;
+      A.z_CaCO3_form[(long long)a * pl + ix] = CaProd;
+      A.z_bSi_form[(long long)a * pl + ix] = photoSi;
+    }
+    // losses (1285-1290)
+    const double loss = t.mort * Pp * Tfunc;
+    double ag = dmin((t.agg_rate_max * DPS) * Pp, t.mort2 * Pp * Pp);
+    ag = dmax((t.agg_rate_min * DPS) * Pp, ag);
+    double Nfix = 0.0;
+    if (t.Nfixer) {   // 1331-1338
+      wk = photoC * QN;
+      Nfix = (wk * R_NFIX_PHOTO) - NO3_V - NH4_V;
+      nexc = nexc + (Nfix + NO3_V + NH4_V - wk);      // Nexcrete, added to NH4 in the sweep (1589-1592)
+      d_totNfix = d_totNfix + Nfix;
+    }
+    ST_KCA(Nfix, a, Nfix);
+    // routing (1354-1386)
+    const double gr_zoo = t.graze_zoo * gz;
+    double gr_poc;
+    if (t.imp_calcifier) gr_poc = gz * dmax((CACO3_POC_MIN * QCa), dmin(SPC_POC_FAC * dmax(1.0, Pp), F_GRAZE_SP_POC_LIM));
+    else gr_poc = t.graze_poc * gz;
+    const double gr_doc = t.graze_doc * gz;
+    const double gr_dic = gz - (gr_zoo + gr_poc + gr_doc);
+    const double ls_poc = t.imp_calcifier ? QCa * loss : t.loss_poc * loss;
+    const double ls_doc = (1.0 - P.parm_labile_ratio) * (loss - ls_poc);
+    const double ls_dic = P.parm_labile_ratio * (loss - ls_poc);
+    // chains in the reference's order
+    if (t.Qp == QP_ZOO_POM) {
+      DOP_prod = DOP_prod + t.Qp * (ls_doc + gr_doc);
+      L_po4_a = L_po4_a + t.Qp * (ls_dic + gr_dic);
+    } else {
+      const double remaining_P = ((gz + loss + ag) * t.Qp) - ((gr_zoo) * QP_ZOO_POM) - ((gr_poc + ls_poc + ag) * QP_ZOO_POM);
+      DOP_prod = DOP_prod + (1.0 - P.parm_labile_ratio) * remaining_P;
+      L_po4_a = L_po4_a + P.parm_labile_ratio * remaining_P;
+    }
+    DOFe_prod = DOFe_prod + Qfe * (ls_doc + gr_doc);
+    PfeLoc = PfeLoc + Qfe * (ag + gr_poc + ls_poc);
+    sNO3V += NO3_V; sNH4V += NH4_V; sPO4V += PO4_V; sDOPV += DOP_V; sPhotoFe += photoFe; sPhotoC += photoC;
+    s_gr_zoo += gr_zoo; s_ls_doc += ls_doc; s_gr_doc += gr_doc; s_ls_dic += ls_dic; s_gr_dic += gr_dic;
+    s_gr_poc += gr_poc; s_agg += ag; s_ls_poc += ls_poc;
+    d_pCNO3 = d_pCNO3 + pC_NO3;
+    L_fe_a = L_fe_a + (Qfe * (ls_dic + gr_dic)) + gr_zoo * (Qfe - QFE_ZOO);                      // 1601-1605
+    if (t.Si_ind > 0) {
+      L_sio3_a = L_sio3_a - photoSi + Qsi * (F_GRAZE_SI_REMIN * gz + (1.0 - t.loss_poc) * loss);   // 1622-1628
+      prodSi = Qsi * ((1.0 - F_GRAZE_SI_REMIN) * gz + ag + t.loss_poc * loss);                    // 1492-1498
+    }
+    if (t.CaCO3_ind > 0) {
+      prodCa = ((1.0 - F_GRAZE_CACO3_REMIN) * gz + loss + ag) * QCa;                              // 1480-1485
+      ca_x = ca_x + F_GRAZE_CACO3_REMIN * gz * QCa;                                               // 1734-1739, 1754-1759
+      ca_prod = ca_prod + CaProd;
+    }
+    if (photoC > 0.0) {   // O2 production (1767-1782)
+      if (!t.Nfixer) {
+        const double den = NO3_V + NH4_V;
+        O2_PRODUCTION = O2_PRODUCTION + photoC * ((NO3_V / den) / RED_D_C_O2 + (NH4_V / den) / REMIN_D_C_O2);
+      } else {
+        const double den = NO3_V + NH4_V + Nfix;
+        O2_PRODUCTION = O2_PRODUCTION + photoC * ((NO3_V / den) / RED_D_C_O2 + (NH4_V / den) / REMIN_D_C_O2 + (Nfix / den) / RED_D_C_O2_DIAZ);
+      }
+    }
+    // autotroph tendencies (1676-1697)
+    wk = gz + loss + ag;
+    const double t_C = photoC - wk;
+    TEND(t.C_ind) = t_C;
+    TEND(t.Chl_ind) = photoacc - thetaC * wk;
+    TEND(t.Fe_ind) = photoFe - Qfe * wk;
+    if (t.Si_ind > 0) { const double v = photoSi - Qsi * wk; TEND(t.Si_ind) = v; sSi = sSi + v; }
+    if (t.CaCO3_ind > 0) { const double v = CaProd - QCa * wk; TEND(t.CaCO3_ind) = v; sCa = sCa + v; }
+    if (DIAG) {
+      ST_KCA(auto_graze, a, gz); ST_KCA(auto_loss, a, loss); ST_KCA(auto_agg, a, ag);
+      sC = sC + t_C; sQpC = sQpC + t.Qp * t_C; sNfix = sNfix + Nfix; chl = chl + p.Chl;
+    }
+  }
+  ST_KC(tot_CaCO3_form, d_totCa);
+  ST_KC(tot_Nfix, d_totNfix);
+  ST_KC(photoC_TOT, sPhotoC);
+  ST_KC(photoC_NO3_TOT, d_pCNO3);
+  ST_KC(auto_graze_TOT, sum4(graze));
+
+  // ---- DOM (1421-1461) ----
+  const double DOC_prod = zoo_loss_doc + s_ls_doc + s_gr_doc;
+  const double DON_prod = QN * DOC_prod;
+  double DOC_remin = DOC * DOC_REMINR, DON_remin = DON * DON_REMINR, DOFe_remin = DOFe * DOFE_REMINR,
+         DOP_remin = DOP * DOP_REMINR, DONr_remin, DOPr_remin;
+  if (PAR_avg > 1.0) {
+    DONr_remin = DONr * DONR_REMINR;
+    DOPr_remin = DOPr * DOPR_REMINR;
+  } else {   // below the euphotic zone (1451-1461)
+    DONr_remin = DONr * (1.0 / (365.0 * 670.0)) * DPS;
+    DOPr_remin = DOPr * (1.0 / (365.0 * 460.0)) * DPS;
+    DOC_remin = DOC_remin * 0.0685;
+    DON_remin = DON_remin * 0.1;
+    DOFe_remin = DOFe_remin * 0.05;
+    DOP_remin = DOP_remin * 0.05;
+  }
+  const double prodPOC = f_zoo_detr * zoo_loss + s_gr_poc + s_agg + s_ls_poc;        // 1467-1468
+
+  // ---- decay factors of the sinking classes across this level (2273-2339) ----
+  double scalelength;
+  {
+    const double* sz = P.parm_scalelen_z;
+    const double* sv = P.parm_scalelen_vals;
+    if (zb < sz[0]) scalelength = sv[0];
+    else if (zb >= sz[3]) scalelength = sv[3];
+    else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
+    else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
+    else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
+  }
+  const double TfuncS = pow(1.5, ((T + T0K) - (TREF + T0K)) / 10.0);
+  double poc_diss = P.parm_POC_diss;
+  if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
+  else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
+  poc_diss = scalelength * poc_diss;
+  double sio2_diss = scalelength * P.parm_SiO2_diss;
+  const double caco3_diss = scalelength * P.parm_CaCO3_diss;
+  const double dust_diss = scalelength * DUST_DISS;
+  sio2_diss = sio2_diss / TfuncS;
+  SCR(S_PRODPOC) = prodPOC; SCR(S_PRODCA) = prodCa; SCR(S_PRODSI) = prodSi; SCR(S_PFELOC) = PfeLoc;
+  SCR(S_DEC_POC) = exp(-dz / poc_diss); SCR(S_DEC_SIO2) = exp(-dz / sio2_diss);
+  SCR(S_DEC_CACO3) = exp(-dz / caco3_diss); SCR(S_DEC_DUST) = exp(-dz / dust_diss);
+  SCR(S_DEC_HARD) = exp(-dz / 4.0e6); SCR(S_DEC_HARDDUST) = exp(-dz / 1.2e7);
+  SCR(S_POC_DISS) = poc_diss; SCR(S_SIO2_DISS) = sio2_diss; SCR(S_CACO3_DISS) = caco3_diss;
+
+  // ---- nitrification (1554-1561) ----
+  double NITRIF;
+  if (PAR_out < P.parm_nitrif_par_lim) {
+    NITRIF = P.parm_kappa_nitrif * NH4;
+    if (PAR_in > P.parm_nitrif_par_lim) NITRIF = NITRIF * log(PAR_out / P.parm_nitrif_par_lim) / (-KPARdz);
+  } else NITRIF = 0.0;
+  SCR(S_DOC_REMIN) = DOC_remin; SCR(S_NITRIF) = NITRIF; SCR(S_ZLD) = zoo_loss_dic; SCR(S_LSDIC) = s_ls_dic;
+  SCR(S_GRDIC) = s_gr_dic; SCR(S_NEXC) = nexc; SCR(S_CAX) = ca_x; SCR(S_CAPROD) = ca_prod;
+
+  // ---- tendencies that do not see the particles (1703-1723) ----
+  const double t_zooC = s_gr_zoo - zoo_loss;
+  const double t_doc = DOC_prod - DOC_remin;
+  const double t_don = (DON_prod * (1.0 - DONREFRACT)) - DON_remin;
+  const double t_dop = (DOP_prod * (1.0 - DOPREFRACT)) - DOP_remin - sDOPV;
+  TEND(P.ind[15]) = t_zooC;
+  TEND(P.ind[9]) = t_doc;
+  TEND(P.ind[10]) = t_don;
+  TEND(P.ind[11]) = DOFe_prod - DOFe_remin;
+  TEND(P.ind[12]) = t_dop;
+  // ---- particle-dependent tendencies: the local part waits in the caller's tendency plane ----
+  TEND(P.ind[1]) = sNO3V;                                                             // 1583
+  TEND(P.ind[3]) = -sNH4V - NITRIF + DON_remin + DONr_remin;                          // 1585
+  TEND(P.ind[4]) = ((QFE_ZOO * zoo_loss_dic) + DOFe_remin - sPhotoFe) + L_fe_a;       // 1598-1605
+  TEND(P.ind[2]) = L_sio3_a;                                                          // 1620-1628
+  TEND(P.ind[0]) = (DOP_remin + DOPr_remin - sPO4V) + L_po4_a;                        // 1643-1661
+  TEND(P.ind[14]) = (DON_prod * DONREFRACT) - DONr_remin;                             // 1714
+  TEND(P.ind[13]) = (DOP_prod * DOPREFRACT) - DOPr_remin;                             // 1720
+  TEND(P.ind[6]) = s_ls_dic + s_gr_dic - sPhotoC + DOC_remin;                         // 1729-1731
+  TEND(P.ind[5]) = O2_PRODUCTION;                                                     // 1790
+
+  if (DIAG) {
+    ST_KC(NO3_RESTORE, 0.0); ST_KC(SiO3_RESTORE, 0.0); ST_KC(PO4_RESTORE, 0.0);       // lrest_* never set (131-134)
+    ST_KC(NITRIF, NITRIF); ST_KC(O2_PRODUCTION, O2_PRODUCTION);
+    if (D.AOU) D.AOU[ix] = o2sat(T, A.salt[ix], T0K) - O2;
+    ST_KC(PAR_avg, PAR_avg); ST_KC(zoo_loss, zoo_loss);
+    ST_KC(DOC_prod, DOC_prod); ST_KC(DOC_remin, DOC_remin); ST_KC(DON_prod, DON_prod); ST_KC(DON_remin, DON_remin);
+    ST_KC(DOP_prod, DOP_prod); ST_KC(DOP_remin, DOP_remin); ST_KC(DOFe_prod, DOFe_prod); ST_KC(DOFe_remin, DOFe_remin);
+    // local parts of the conservation integrals (1875-1938); the sweep adds the particle-dependent tendencies
+    const double ztop = (k > 0) ? A.zbot[g.at(k - 1, c)] : 0.0;
+    w2 = dmin(100.0e2 - ztop, dz);
+    const double pt100 = (w2 > 0.0) ? w2 : 0.0;
+    SCR(S_JC) = t_doc + t_zooC + sC + sCa;
+    SCR(S_JN) = t_don + QN * t_zooC + QN * sC - sNfix;
+    SCR(S_JP) = t_dop + QP_ZOO_POM * t_zooC + sQpC;
+    SCR(S_JSI) = sSi;
+    SCR(S_CHL100) = chl * pt100;
+  }
+#undef TRC
+#undef TEND
+#undef SCR
+#undef ST_KC
+#undef ST_KCA
+}
+
+// ------------------------------------------------------------------------------ particle sweep
+struct Flux { double s, h; };   // soft / hard sub-class flux leaving a level
+
+// Everything one level of the sweep reads.  The loads do not depend on the recurrence, so the next level's
+// set is requested before the current level is evaluated (one wave per SIMD cannot hide HBM latency any
+// other way: 100k columns are only 1 563 wavefronts).
+template <bool DIAG>
+struct LevelIn {
+  double dz, zb, fesed, NO3, Fe, O2;
+  double prodPOC, prodCa, prodSi, PfeLoc, dPOC, dSi, dCa, dDust, dHard, dHardDust, poc_diss, sio2_diss, caco3_diss;
+  double DOC_remin, NITRIF, zld, lsdic, grdic, nexc, ca_x, ca_prod;
+  double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_o2;
+  double jc, jn, jp, jsi;   // DIAG only
+};
+
+template <bool DIAG>
+__device__ __forceinline__ void load_level(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, LevelIn<DIAG>& L) {
+  const long long pl = A.g.plane, sp = A.splane;
+#define TRC(slot) dmax(0.0, A.tracers[(long long)((slot)-1) * pl + ix])
+#define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
+#define SCR(s) A.scratch[(long long)(s) * sp + ix]
+  L.dz = A.dz[ix]; L.zb = A.zbot[ix]; L.fesed = A.fesed[ix];
+  L.NO3 = TRC(P.ind[1]); L.Fe = TRC(P.ind[4]); L.O2 = TRC(P.ind[5]);
+  L.prodPOC = SCR(S_PRODPOC); L.prodCa = SCR(S_PRODCA); L.prodSi = SCR(S_PRODSI); L.PfeLoc = SCR(S_PFELOC);
+  L.dPOC = SCR(S_DEC_POC); L.dSi = SCR(S_DEC_SIO2); L.dCa = SCR(S_DEC_CACO3); L.dDust = SCR(S_DEC_DUST);
+  L.dHard = SCR(S_DEC_HARD); L.dHardDust = SCR(S_DEC_HARDDUST);
+  L.poc_diss = SCR(S_POC_DISS); L.sio2_diss = SCR(S_SIO2_DISS); L.caco3_diss = SCR(S_CACO3_DISS);
+  L.DOC_remin = SCR(S_DOC_REMIN); L.NITRIF = SCR(S_NITRIF); L.zld = SCR(S_ZLD); L.lsdic = SCR(S_LSDIC); L.grdic = SCR(S_GRDIC);
+  L.nexc = SCR(S_NEXC); L.ca_x = SCR(S_CAX); L.ca_prod = SCR(S_CAPROD);
+  L.L_no3 = TEND(P.ind[1]); L.L_nh4 = TEND(P.ind[3]); L.L_fe = TEND(P.ind[4]); L.L_sio3 = TEND(P.ind[2]); L.L_po4 = TEND(P.ind[0]);
+  L.L_donr = TEND(P.ind[14]); L.L_dopr = TEND(P.ind[13]); L.L_dic = TEND(P.ind[6]); L.L_o2 = TEND(P.ind[5]);
+  if (DIAG) { L.jc = SCR(S_JC); L.jn = SCR(S_JN); L.jp = SCR(S_JP); L.jsi = SCR(S_JSI); }
+#undef TRC
+#undef TEND
+#undef SCR
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  const GridView& g = A.g;
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if (c >= g.ncol) return;
+  const obgc_bgc_diag& D = A.diag;
   const long long pl = g.plane;
   int kmax = A.kmax[c];
   if (kmax > g.nlev) kmax = g.nlev;
 
-#define TRC(slot, ix) dmax(0.0, A.tracers[(long long)((slot)-1) * pl + (ix)])
 #define TEND(slot, ix) A.tend[(long long)((slot)-1) * pl + (ix)]
 #define ST_KC(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
-#define ST_KCA(name, a, v) do { if (DIAG && D.name) D.name[(long long)(a) * pl + ix] = (v); } while (0)
 #define ST_C(name, v) do { if (DIAG && D.name) D.name[c] = (v); } while (0)
-#define ST_CA(name, a, v) do { if (DIAG && D.name) D.name[(long long)(a) * g.ldc + c] = (v); } while (0)
 
-  // ---- per-column initialisation (BGC_mod.F90:808-814, 2075-2104) ----
-  const double lat = A.lat[c];
-  const bool north = lat >= 0.0, south_or_eq = lat <= 0.0;
+  // ---- per-column initialisation (BGC_mod.F90:808-811, 2075-2104) ----
   const double dust_in = (kmax >= 1) ? dmax(0.0, A.dust[c]) : 0.0;
   Flux fPOC{0.0, 0.0}, fCa{0.0, 0.0}, fSi{0.0, 0.0}, fFe{0.0, 0.0}, fDust{0.0, 0.0};
   if (dust_in != 0.0) { fDust.s = (1.0 - DUST_GAMMA) * dust_in; fDust.h = DUST_GAMMA * dust_in; }
   double QA_dust_def = DUST_RHO * (fDust.s + fDust.h);
-  double PAR_out = (kmax >= 1) ? dmax(0.0, A.sw[c]) * F_QSW_PAR : 0.0;
-  double prodCa = 0.0, prodSi = 0.0;   // keep their value when no autotroph calcifies / silicifies (1480-1498)
-
-  // running column diagnostics
-  double z_bSi = 0.0, z_CaTot = 0.0, z_pCTot = 0.0, z_pCNO3Tot = 0.0, z_Chl100 = 0.0;
-  double z_Ca[4] = {0, 0, 0, 0}, z_pC[4] = {0, 0, 0, 0}, z_pCNO3[4] = {0, 0, 0, 0};
   double J_C = 0, J_C100 = 0, J_N = 0, J_N100 = 0, J_P = 0, J_P100 = 0, J_Si = 0, J_Si100 = 0;
-  double o2min = 0.0, o2min_z = 0.0, zbot_above = 0.0;
+  double zbot_above = 0.0;
 
+  LevelIn<DIAG> cur, nxt;
+  if (kmax >= 1) load_level<DIAG>(A, P, g.at(0, c), cur);
   for (int k = 0; k < kmax; ++k) {
     const long long ix = g.at(k, c);
-    const double T = A.temp[ix], S = A.salt[ix], dz = A.dz[ix], zc = A.zmid[ix], zb = A.zbot[ix];
-    // clamped local copies (747-762)
-    const double PO4 = TRC(P.ind[0], ix), NO3 = TRC(P.ind[1], ix), SiO3 = TRC(P.ind[2], ix), NH4 = TRC(P.ind[3], ix),
-                 Fe = TRC(P.ind[4], ix), O2 = TRC(P.ind[5], ix), DOC = TRC(P.ind[9], ix), DON = TRC(P.ind[10], ix),
-                 DOFe = TRC(P.ind[11], ix), DOP = TRC(P.ind[12], ix), DOPr = TRC(P.ind[13], ix),
-                 DONr = TRC(P.ind[14], ix), zooC = TRC(P.ind[15], ix);
-    double aChl[4], aC[4], aFe[4], aSi[4], aCa[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      aChl[a] = TRC(at[a].Chl_ind, ix);
-      aC[a] = TRC(at[a].C_ind, ix);
-      aFe[a] = TRC(at[a].Fe_ind, ix);
-      aSi[a] = (at[a].Si_ind > 0) ? TRC(at[a].Si_ind, ix) : 0.0;
-      aCa[a] = (at[a].CaCO3_ind > 0) ? TRC(at[a].CaCO3_ind, ix) : 0.0;
-    }
-    // O2 minimum (1954-1968) folded into the sweep
-    if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = zc; }
-
-    // zero-mask: an autotroph with any empty pool is empty (826-844), then quotas (850-898)
-    double thetaC[4], Qfe[4], Qsi[4], gQfe[4], gQsi[4], QCa[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      bool empty = aChl[a] == 0.0 || aC[a] == 0.0 || aFe[a] == 0.0;
-      if (at[a].Si_ind > 0) empty = empty || aSi[a] == 0.0;
-      if (empty) { aChl[a] = 0.0; aC[a] = 0.0; aFe[a] = 0.0; aSi[a] = 0.0; aCa[a] = 0.0; }
-      const double Cden = aC[a] + EPSC;
-      thetaC[a] = aChl[a] / Cden;
-      Qfe[a] = aFe[a] / Cden;
-      Qsi[a] = (at[a].Si_ind > 0) ? dmin(aSi[a] / Cden, GQSI_MAX) : 0.0;
-      gQfe[a] = at[a].gQfe_0;
-      if (Fe < CKS * at[a].kFe) gQfe[a] = dmax((gQfe[a] * Fe / (CKS * at[a].kFe)), at[a].gQfe_min);
-      gQsi[a] = 0.0;
-      if (at[a].Si_ind > 0) {
-        gQsi[a] = GQSI_0;
-        if ((Fe < CKSI * at[a].kFe) && (Fe > 0.0) && (SiO3 > (CKSI * at[a].kSiO3)))
-          gQsi[a] = dmin((gQsi[a] * CKSI * at[a].kFe / Fe), GQSI_MAX);
-        if (Fe == 0.0) gQsi[a] = GQSI_MAX;
-        if (SiO3 < (CKSI * at[a].kSiO3)) gQsi[a] = dmax((gQsi[a] * SiO3 / (CKSI * at[a].kSiO3)), GQSI_MIN);
-      }
-      QCa[a] = 0.0;
-      if (at[a].CaCO3_ind > 0) {
-        QCa[a] = aCa[a] / Cden;
-        if (QCa[a] > QCACO3_MAX) QCa[a] = QCACO3_MAX;
-      }
-    }
-
-    // light (907-924)
-    const double PAR_in = PAR_out;
-    double w1 = dmax(sum4(aChl), 0.02);
-    double KPARdz = (w1 < 0.13224) ? 0.000919 * pow(w1, 0.3536) : 0.001131 * pow(w1, 0.4562);
-    KPARdz = KPARdz * dz;
-    const double att = exp(-KPARdz);
-    PAR_out = PAR_in * att;
-    const double PAR_avg = PAR_in * (1.0 - att) / KPARdz;
-
-    // temperature response and loss thresholds (1041-1094)
-    const double Tfunc = pow(Q_10, ((T + T0K) - (TREF + T0K)) / 10.0);
-    double f_loss_thres;
-    if (zc > THRES_Z1) f_loss_thres = (zc < THRES_Z2) ? (THRES_Z2 - zc) / (THRES_Z2 - THRES_Z1) : 0.0;
-    else f_loss_thres = 1.0;
-    double Pprime[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double C_loss_thres = f_loss_thres * at[a].loss_thres;
-      if (at[a].temp_function == TFNC_Q10) {
-        if (T < at[a].temp_thres) C_loss_thres = f_loss_thres * at[a].loss_thres2;
-      } else if (at[a].temp_function == TFNC_QUASI_MMRT) {
-        const double tmpTmax = north ? at[a].temp_thresN : at[a].temp_thresS;
-        if (T > tmpTmax) C_loss_thres = f_loss_thres * at[a].loss_thres2;
-      }
-      Pprime[a] = dmax(aC[a] - C_loss_thres, 0.0);
-    }
-
-    // ---- autotroph kinetics (1107-1388) ----
-    double NO3_V[4], NH4_V[4], PO4_V[4], DOP_V[4], photoC[4], photoFe[4], photoSi[4], CaProd[4], photoacc[4], Nfix[4],
-        Nexc[4], loss[4], agg[4], graze[4], gr_zoo[4], gr_poc[4], gr_doc[4], gr_dic[4], ls_poc[4], ls_doc[4], ls_dic[4],
-        remP_dop[4], remP_dip[4], pC_NO3[4];
-    double d_totCa = 0.0, d_totNfix = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double rNO3 = NO3 / at[a].kNO3, rNH4 = NH4 / at[a].kNH4;
-      const double VNO3 = rNO3 / (1.0 + rNO3 + rNH4);
-      const double VNH4 = rNH4 / (1.0 + rNO3 + rNH4);
-      double VNtot = VNO3 + VNH4;
-      if (at[a].Nfixer) VNtot = 1.0;
-      ST_KCA(N_lim, a, VNtot);
-      const double VFe = Fe / (Fe + at[a].kFe);
-      ST_KCA(Fe_lim, a, VFe);
-      double f_nut = dmin(VNtot, VFe);
-      const double rPO4 = PO4 / at[a].kPO4, rDOP = DOP / at[a].kDOP;
-      const double VPO4 = rPO4 / (1.0 + rPO4 + rDOP);
-      const double VDOP = rDOP / (1.0 + rPO4 + rDOP);
-      const double VPtot = VPO4 + VDOP;
-      ST_KCA(P_lim, a, VPtot);
-      f_nut = dmin(f_nut, VPtot);
-      if (at[a].kSiO3 > 0.0) {
-        const double VSiO3 = SiO3 / (SiO3 + at[a].kSiO3);
-        ST_KCA(SiO3_lim, a, VSiO3);
-        f_nut = dmin(f_nut, VSiO3);
-      } else {
-        ST_KCA(SiO3_lim, a, 0.0);
-      }
-      double PCmax = at[a].PCref * f_nut * Tfunc;
-      if (T < at[a].temp_thres) PCmax = 0.0;
-      if (at[a].temp_function == TFNC_QUASI_MMRT) {
-        const double tmpTopt = north ? at[a].temp_optN : at[a].temp_optS;
-        const double tmpTmax = north ? at[a].temp_thresN : at[a].temp_thresS;
-        PCmax = PCmax * dmin(1.0, ((tmpTmax - T) / (tmpTmax - tmpTopt)));
-        if (T > tmpTmax) PCmax = 0.0;
-      }
-      const double light_lim = (1.0 - exp((-1.0 * at[a].alphaPI * thetaC[a] * PAR_avg) / (PCmax + EPSTINV)));
-      const double PCphoto = PCmax * light_lim;
-      ST_KCA(light_lim, a, light_lim);
-      photoC[a] = PCphoto * aC[a];
-      double VNC;
-      if (VNtot > 0.0) {
-        NO3_V[a] = (VNO3 / VNtot) * photoC[a] * QN;
-        NH4_V[a] = (VNH4 / VNtot) * photoC[a] * QN;
-        VNC = PCphoto * QN;
-        pC_NO3[a] = (VNO3 / VNtot) * photoC[a];            // 1828-1834
-      } else { NO3_V[a] = 0.0; NH4_V[a] = 0.0; VNC = 0.0; pC_NO3[a] = 0.0; }
-      ST_KCA(photoNO3, a, NO3_V[a]);
-      ST_KCA(photoNH4, a, NH4_V[a]);
-      if (VPtot > 0.0) {
-        PO4_V[a] = (VPO4 / VPtot) * photoC[a] * at[a].Qp;
-        DOP_V[a] = (VDOP / VPtot) * photoC[a] * at[a].Qp;
-      } else { PO4_V[a] = 0.0; DOP_V[a] = 0.0; }
-      ST_KCA(PO4_uptake, a, PO4_V[a]);
-      ST_KCA(DOP_uptake, a, DOP_V[a]);
-      photoFe[a] = photoC[a] * gQfe[a];
-      ST_KCA(photoFe, a, photoFe[a]);
-      photoSi[a] = 0.0;
-      if (at[a].Si_ind > 0) {
-        photoSi[a] = photoC[a] * gQsi[a];
-        z_bSi = z_bSi + photoSi[a];
-      }
-      ST_KCA(bSi_form, a, photoSi[a]);
-      w1 = at[a].alphaPI * thetaC[a] * PAR_avg;
-      if (w1 > 0.0) {
-        const double pChl = at[a].thetaN_max * PCphoto / w1;
-        photoacc[a] = (pChl * VNC / thetaC[a]) * aChl[a];
-      } else photoacc[a] = 0.0;
-      CaProd[a] = 0.0;
-      if (at[a].imp_calcifier) {
-        double cp = P.parm_f_prod_sp_CaCO3 * photoC[a];
-        cp = cp * f_nut;
-        if (T < CACO3_TEMP_THRES1) cp = cp * dmax((T - CACO3_TEMP_THRES2), 0.0) / (CACO3_TEMP_THRES1 - CACO3_TEMP_THRES2);
-        if (aC[a] > CACO3_SP_THRES) cp = dmin((cp * aC[a] / CACO3_SP_THRES), (F_PHOTOSP_CACO3 * photoC[a]));
-        CaProd[a] = cp;
-        d_totCa = d_totCa + cp;
-        w1 = dz * cp;
-        z_Ca[a] = z_Ca[a] + w1;
-        z_CaTot = z_CaTot + w1;
-      }
-      ST_KCA(CaCO3_form, a, CaProd[a]);
-      loss[a] = at[a].mort * Pprime[a] * Tfunc;
-      agg[a] = dmin((at[a].agg_rate_max * DPS) * Pprime[a], at[a].mort2 * Pprime[a] * Pprime[a]);
-      agg[a] = dmax((at[a].agg_rate_min * DPS) * Pprime[a], agg[a]);
-      // grazing on the grazee class this autotroph belongs to (1297-1324)
-      w1 = 0.0;
-#pragma unroll
-      for (int a2 = 0; a2 < 4; ++a2)
-        if (at[a2].grazee_ind == at[a].grazee_ind) w1 = w1 + Pprime[a2];
-      double z_umax = at[a].z_umax_0 * Tfunc;
-      if (a + 1 == P.diat_ind) {
-        if (north && (T > at[a].temp_optN))
-          z_umax = z_umax * dmax((at[a].temp_thresN - T) / (at[a].temp_thresN - at[a].temp_optN), 0.95);
-        else if (south_or_eq && (T > at[a].temp_optS))
-          z_umax = z_umax * dmax((at[a].temp_thresS - T) / (at[a].temp_thresS - at[a].temp_optS), 0.95);
-      }
-      graze[a] = (w1 > 0.0) ? (Pprime[a] / w1) * z_umax * zooC * (w1 / (w1 + at[a].z_grz)) : 0.0;
-      Nfix[a] = 0.0; Nexc[a] = 0.0;
-      if (at[a].Nfixer) {
-        w1 = photoC[a] * QN;
-        Nfix[a] = (w1 * R_NFIX_PHOTO) - NO3_V[a] - NH4_V[a];
-        Nexc[a] = Nfix[a] + NO3_V[a] + NH4_V[a] - w1;
-        d_totNfix = d_totNfix + Nfix[a];
-      }
-      ST_KCA(Nfix, a, Nfix[a]);
-      // routing (1354-1386)
-      gr_zoo[a] = at[a].graze_zoo * graze[a];
-      if (at[a].imp_calcifier)
-        gr_poc[a] = graze[a] * dmax((CACO3_POC_MIN * QCa[a]), dmin(SPC_POC_FAC * dmax(1.0, Pprime[a]), F_GRAZE_SP_POC_LIM));
-      else gr_poc[a] = at[a].graze_poc * graze[a];
-      gr_doc[a] = at[a].graze_doc * graze[a];
-      gr_dic[a] = graze[a] - (gr_zoo[a] + gr_poc[a] + gr_doc[a]);
-      ls_poc[a] = at[a].imp_calcifier ? QCa[a] * loss[a] : at[a].loss_poc * loss[a];
-      ls_doc[a] = (1.0 - P.parm_labile_ratio) * (loss[a] - ls_poc[a]);
-      ls_dic[a] = P.parm_labile_ratio * (loss[a] - ls_poc[a]);
-      remP_dop[a] = 0.0; remP_dip[a] = 0.0;
-      if (at[a].Qp != QP_ZOO_POM) {
-        const double remaining_P = ((graze[a] + loss[a] + agg[a]) * at[a].Qp) - ((gr_zoo[a]) * QP_ZOO_POM) -
-                                   ((gr_poc[a] + ls_poc[a] + agg[a]) * QP_ZOO_POM);
-        remP_dop[a] = (1.0 - P.parm_labile_ratio) * remaining_P;
-        remP_dip[a] = P.parm_labile_ratio * remaining_P;
-      }
-    }
-    ST_KC(tot_CaCO3_form, d_totCa);
-    ST_KC(tot_Nfix, d_totNfix);
-
-    // ---- zooplankton, DOM, detritus production (1395-1500) ----
-    w1 = 0.0;
-    double w2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      w1 = w1 + at[a].f_zoo_detr * (graze[a] + EPSC * EPSTINV);
-      w2 = w2 + (graze[a] + EPSC * EPSTINV);
-    }
-    const double f_zoo_detr = w1 / w2;
-    const double Zprime = dmax(zooC - f_loss_thres * LOSS_THRES_ZOO, 0.0);
-    const double zoo_loss = (P.parm_z_mort2_0 * pow(Zprime, 1.5) + P.parm_z_mort_0 * Zprime) * Tfunc;
-    const double zoo_loss_doc = (1.0 - P.parm_labile_ratio) * (1.0 - f_zoo_detr) * zoo_loss;
-    const double zoo_loss_dic = P.parm_labile_ratio * (1.0 - f_zoo_detr) * zoo_loss;
-    const double DOC_prod = zoo_loss_doc + sum4(ls_doc) + sum4(gr_doc);
-    const double DON_prod = QN * DOC_prod;
-    double DOP_prod = QP_ZOO_POM * zoo_loss_doc;
-    double DOFe_prod = QFE_ZOO * zoo_loss_doc;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (at[a].Qp == QP_ZOO_POM) DOP_prod = DOP_prod + at[a].Qp * (ls_doc[a] + gr_doc[a]);
-      else DOP_prod = DOP_prod + remP_dop[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) DOFe_prod = DOFe_prod + Qfe[a] * (ls_doc[a] + gr_doc[a]);
-    double DOC_remin = DOC * DOC_REMINR, DON_remin = DON * DON_REMINR, DOFe_remin = DOFe * DOFE_REMINR,
-           DOP_remin = DOP * DOP_REMINR, DONr_remin, DOPr_remin;
-    if (PAR_avg > 1.0) {
-      DONr_remin = DONr * DONR_REMINR;
-      DOPr_remin = DOPr * DOPR_REMINR;
-    } else {   // below the euphotic zone (1451-1461)
-      DONr_remin = DONr * (1.0 / (365.0 * 670.0)) * DPS;
-      DOPr_remin = DOPr * (1.0 / (365.0 * 460.0)) * DPS;
-      DOC_remin = DOC_remin * 0.0685;
-      DON_remin = DON_remin * 0.1;
-      DOFe_remin = DOFe_remin * 0.05;
-      DOP_remin = DOP_remin * 0.05;
-    }
-    const double prodPOC = f_zoo_detr * zoo_loss + sum4(gr_poc) + sum4(agg) + sum4(ls_poc);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (at[a].CaCO3_ind > 0) prodCa = ((1.0 - F_GRAZE_CACO3_REMIN) * graze[a] + loss[a] + agg[a]) * QCa[a];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (at[a].Si_ind > 0) prodSi = Qsi[a] * ((1.0 - F_GRAZE_SI_REMIN) * graze[a] + agg[a] + at[a].loss_poc * loss[a]);
+    if (k + 1 < kmax) load_level<DIAG>(A, P, g.at(k + 1, c), nxt);   // in flight while this level is evaluated
+    const double dz = cur.dz, zb = cur.zb, NO3 = cur.NO3, Fe = cur.Fe, O2 = cur.O2;
+    const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
+    const double decay_POC_E = cur.dPOC, decay_SiO2 = cur.dSi, decay_CaCO3 = cur.dCa, decay_dust = cur.dDust,
+                 DECAY_Hard = cur.dHard, DECAY_HardDust = cur.dHardDust, poc_diss = cur.poc_diss, sio2_diss = cur.sio2_diss,
+                 caco3_diss = cur.caco3_diss;
+    const double DOC_remin = cur.DOC_remin, NITRIF = cur.NITRIF, zoo_loss_dic = cur.zld, s_ls_dic = cur.lsdic, s_gr_dic = cur.grdic;
 
     // iron scavenging onto the particles LEAVING the level above (1510-1529)
     double Fe_scav_rate = P.parm_fe_scavenge_rate0;
@@ -351,36 +635,12 @@ __global__ __launch_bounds__(kBlock) void bgc_ecosys_kernel(const BgcKernelArgs 
                                    (fDust.s + fDust.h) * DUST_FESCAV_SCALE);
     if (Fe > FE_SCAV_THRES1) Fe_scav_rate = Fe_scav_rate + (Fe - FE_SCAV_THRES1) * FE_MAX_SCALE2;
     const double Fe_scavenge = YPS * Fe * Fe_scav_rate;
-    double prodFe = (zoo_loss * f_zoo_detr * QFE_ZOO) + Fe_scavenge;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) prodFe = prodFe + Qfe[a] * (agg[a] + gr_poc[a] + ls_poc[a]);
+    const double prodFe = cur.PfeLoc + Fe_scavenge;
 
-    // ---- sinking particles: one step of the Armstrong et al. ballast recurrence (2242-2501) ----
+    // one step of the Armstrong et al. ballast recurrence (2242-2501)
     const Flux inPOC = fPOC, inCa = fCa, inSi = fSi, inFe = fFe, inDust = fDust;
     double sedPOC = 0.0, sedCa = 0.0, sedSi = 0.0, sedDust = 0.0, sedFe = 0.0, SED_DENITRIF = 0.0, OTHER_REMIN = 0.0;
-    double scalelength;
-    {
-      const double* sz = P.parm_scalelen_z;
-      const double* sv = P.parm_scalelen_vals;
-      if (zb < sz[0]) scalelength = sv[0];
-      else if (zb >= sz[3]) scalelength = sv[3];
-      else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
-      else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
-      else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
-    }
-    const double DECAY_Hard = exp(-dz / 4.0e6), DECAY_HardDust = exp(-dz / 1.2e7);
-    const double TfuncS = pow(1.5, ((T + T0K) - (TREF + T0K)) / 10.0);
     const double dzr = 1.0 / dz;
-    double poc_diss = P.parm_POC_diss;
-    if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
-    else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
-    poc_diss = scalelength * poc_diss;
-    double sio2_diss = scalelength * P.parm_SiO2_diss;
-    const double caco3_diss = scalelength * P.parm_CaCO3_diss;
-    const double dust_diss = scalelength * DUST_DISS;
-    sio2_diss = sio2_diss / TfuncS;
-    const double decay_POC_E = exp(-dz / poc_diss), decay_SiO2 = exp(-dz / sio2_diss), decay_CaCO3 = exp(-dz / caco3_diss),
-                 decay_dust = exp(-dz / dust_diss);
     fCa.s = inCa.s * decay_CaCO3 + prodCa * ((1.0 - CACO3_GAMMA) * (1.0 - decay_CaCO3) * caco3_diss);
     fCa.h = inCa.h * DECAY_Hard + prodCa * (CACO3_GAMMA * dz);
     fSi.s = inSi.s * decay_SiO2 + prodSi * ((1.0 - SIO2_GAMMA) * (1.0 - decay_SiO2) * sio2_diss);
@@ -415,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void bgc_ecosys_kernel(const BgcKernelArgs 
       fFe.s = 0.0;
       reminFe = inFe.s * dzr + (1.0 - 0.0) * prodFe;
     }
-    reminFe = reminFe + reminDust * DUST_TO_FE + (A.fesed[ix] * dzr);
+    reminFe = reminFe + reminDust * DUST_TO_FE + (cur.fesed * dzr);
     fFe.h = inFe.h;
 
     if (k == kmax - 1) {   // sea floor: burial, sediment denitrification, instantaneous remin (2522-2631)
@@ -445,7 +705,39 @@ __global__ __launch_bounds__(kBlock) void bgc_ecosys_kernel(const BgcKernelArgs 
       sedDust = fDust.s + fDust.h;
       fCa = Flux{0.0, 0.0}; fSi = Flux{0.0, 0.0}; fDust = Flux{0.0, 0.0}; fPOC = Flux{0.0, 0.0}; fFe = Flux{0.0, 0.0};
     }
-    if (DIAG) {   // 2637-2694
+
+    // ---- denitrification (1569-1577) and the particle-dependent tendencies (1583-1790) ----
+    double w1 = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
+    w1 = dmin(dmax(w1, 0.0), 1.0);
+    if (NO3 == 0.0) w1 = 0.0;
+    const double DENITRIF = w1 * ((DOC_remin + reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
+    const double t_no3 = 0.0 + NITRIF - DENITRIF - SED_DENITRIF - cur.L_no3;
+    const double t_nh4 = cur.L_nh4 + QN * (zoo_loss_dic + s_ls_dic + s_gr_dic + reminPOC * (1.0 - DONREFRACT)) + cur.nexc;
+    const double t_fe = (reminFe + cur.L_fe) - Fe_scavenge;
+    const double t_sio3 = reminSi + cur.L_sio3;
+    const double t_po4 = cur.L_po4 + QP_ZOO_POM * ((1.0 - DOPREFRACT) * reminPOC + zoo_loss_dic);
+    const double t_donr = cur.L_donr + (reminPOC * DONREFRACT * QN);
+    const double t_dopr = cur.L_dopr + (reminPOC * DOPREFRACT * QP_ZOO_POM);
+    const double t_dic = (cur.L_dic + reminPOC + zoo_loss_dic + reminCa) + cur.ca_x - cur.ca_prod;
+    const double t_alk = (-t_no3 + t_nh4 + 2.0 * reminCa) + 2.0 * (cur.ca_x - cur.ca_prod);
+    w1 = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
+    w1 = dmin(dmax(w1, 0.0), 1.0);
+    const double O2_CONSUMPTION =
+        w1 * ((reminPOC + DOC_remin - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN + zoo_loss_dic + s_ls_dic + s_gr_dic) / REMIN_D_C_O2 +
+              (2.0 * NITRIF));
+    TEND(P.ind[1], ix) = t_no3;
+    TEND(P.ind[3], ix) = t_nh4;
+    TEND(P.ind[4], ix) = t_fe;
+    TEND(P.ind[2], ix) = t_sio3;
+    TEND(P.ind[0], ix) = t_po4;
+    TEND(P.ind[14], ix) = t_donr;
+    TEND(P.ind[13], ix) = t_dopr;
+    TEND(P.ind[6], ix) = t_dic;
+    TEND(P.ind[7], ix) = A.alt_co2_use_eco ? t_dic : 0.0;
+    TEND(P.ind[8], ix) = t_alk;
+    TEND(P.ind[5], ix) = cur.L_o2 - O2_CONSUMPTION;
+
+    if (DIAG) {   // 2637-2694, 1563-1577, 1866-1868
       ST_KC(POC_FLUX_IN, inPOC.s + inPOC.h); ST_KC(POC_PROD, prodPOC); ST_KC(POC_REMIN, reminPOC);
       ST_KC(CaCO3_FLUX_IN, inCa.s + inCa.h); ST_KC(CaCO3_PROD, prodCa); ST_KC(CaCO3_REMIN, reminCa);
       ST_KC(SiO2_FLUX_IN, inSi.s + inSi.h); ST_KC(SiO2_PROD, prodSi); ST_KC(SiO2_REMIN, reminSi);
@@ -455,217 +747,124 @@ __global__ __launch_bounds__(kBlock) void bgc_ecosys_kernel(const BgcKernelArgs 
       ST_KC(SedDenitrif, SED_DENITRIF * dz); ST_KC(OtherRemin, OTHER_REMIN * dz);
       ST_KC(ponToSed, (sedPOC * QN)); ST_KC(popToSed, (sedPOC * QP_ZOO_POM));
       ST_KC(dustToSed, sedDust); ST_KC(pfeToSed, sedFe);
-    }
-
-    // ---- nitrification / denitrification (1545-1577) ----
-    const double RESTORE = 0.0;   // lrest_* are never set by the reference (BGC_mod.F90:131-134)
-    double NITRIF;
-    if (PAR_out < P.parm_nitrif_par_lim) {
-      NITRIF = P.parm_kappa_nitrif * NH4;
-      if (PAR_in > P.parm_nitrif_par_lim) NITRIF = NITRIF * log(PAR_out / P.parm_nitrif_par_lim) / (-KPARdz);
-    } else NITRIF = 0.0;
-    w1 = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
-    w1 = dmin(dmax(w1, 0.0), 1.0);
-    if (NO3 == 0.0) w1 = 0.0;
-    const double DENITRIF = w1 * ((DOC_remin + reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
-
-    // ---- tendencies (1583-1790) ----
-    const double s_ls_dic = sum4(ls_dic), s_gr_dic = sum4(gr_dic);
-    const double t_no3 = RESTORE + NITRIF - DENITRIF - SED_DENITRIF - sum4(NO3_V);
-    double t_nh4 = -sum4(NH4_V) - NITRIF + DON_remin + DONr_remin +
-                   QN * (zoo_loss_dic + s_ls_dic + s_gr_dic + reminPOC * (1.0 - DONREFRACT));
-    double t_fe = reminFe + (QFE_ZOO * zoo_loss_dic) + DOFe_remin - sum4(photoFe) - Fe_scavenge;
-    double t_sio3 = RESTORE + reminSi;
-    double t_po4 = RESTORE + DOP_remin + DOPr_remin - sum4(PO4_V) + QP_ZOO_POM * ((1.0 - DOPREFRACT) * reminPOC + zoo_loss_dic);
-    double t_dic = s_ls_dic + s_gr_dic - sum4(photoC) + DOC_remin + reminPOC + zoo_loss_dic + reminCa;
-    double t_C[4], t_Si[4], t_Ca[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (at[a].Nfixer) t_nh4 = t_nh4 + Nexc[a];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) t_fe = t_fe + (Qfe[a] * (ls_dic[a] + gr_dic[a])) + gr_zoo[a] * (Qfe[a] - QFE_ZOO);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (at[a].Si_ind > 0)
-        t_sio3 = t_sio3 - photoSi[a] + Qsi[a] * (F_GRAZE_SI_REMIN * graze[a] + (1.0 - at[a].loss_poc) * loss[a]);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (at[a].Qp == QP_ZOO_POM) t_po4 = t_po4 + at[a].Qp * (ls_dic[a] + gr_dic[a]);
-      else t_po4 = t_po4 + remP_dip[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      w1 = graze[a] + loss[a] + agg[a];
-      t_C[a] = photoC[a] - w1;
-      TEND(at[a].C_ind, ix) = t_C[a];
-      TEND(at[a].Chl_ind, ix) = photoacc[a] - thetaC[a] * w1;
-      TEND(at[a].Fe_ind, ix) = photoFe[a] - Qfe[a] * w1;
-      t_Si[a] = 0.0; t_Ca[a] = 0.0;
-      if (at[a].Si_ind > 0) { t_Si[a] = photoSi[a] - Qsi[a] * w1; TEND(at[a].Si_ind, ix) = t_Si[a]; }
-      if (at[a].CaCO3_ind > 0) { t_Ca[a] = CaProd[a] - QCa[a] * w1; TEND(at[a].CaCO3_ind, ix) = t_Ca[a]; }
-    }
-    const double t_zooC = sum4(gr_zoo) - zoo_loss;
-    const double t_doc = DOC_prod - DOC_remin;
-    const double t_don = (DON_prod * (1.0 - DONREFRACT)) - DON_remin;
-    const double t_donr = (DON_prod * DONREFRACT) - DONr_remin + (reminPOC * DONREFRACT * QN);
-    const double t_dop = (DOP_prod * (1.0 - DOPREFRACT)) - DOP_remin - sum4(DOP_V);
-    const double t_dopr = (DOP_prod * DOPREFRACT) - DOPr_remin + (reminPOC * DOPREFRACT * QP_ZOO_POM);
-    const double t_dofe = DOFe_prod - DOFe_remin;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (at[a].CaCO3_ind > 0) t_dic = t_dic + F_GRAZE_CACO3_REMIN * graze[a] * QCa[a] - CaProd[a];
-    double t_alk = -t_no3 + t_nh4 + 2.0 * reminCa;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (at[a].CaCO3_ind > 0) t_alk = t_alk + 2.0 * (F_GRAZE_CACO3_REMIN * graze[a] * QCa[a] - CaProd[a]);
-    double O2_PRODUCTION = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (photoC[a] > 0.0) {
-        if (!at[a].Nfixer) {
-          const double den = NO3_V[a] + NH4_V[a];
-          O2_PRODUCTION = O2_PRODUCTION + photoC[a] * ((NO3_V[a] / den) / RED_D_C_O2 + (NH4_V[a] / den) / REMIN_D_C_O2);
-        } else {
-          const double den = NO3_V[a] + NH4_V[a] + Nfix[a];
-          O2_PRODUCTION = O2_PRODUCTION + photoC[a] * ((NO3_V[a] / den) / RED_D_C_O2 + (NH4_V[a] / den) / REMIN_D_C_O2 +
-                                                       (Nfix[a] / den) / RED_D_C_O2_DIAZ);
-        }
-      }
-    }
-    w1 = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
-    w1 = dmin(dmax(w1, 0.0), 1.0);
-    const double O2_CONSUMPTION =
-        w1 * ((reminPOC + DOC_remin - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN + zoo_loss_dic + s_ls_dic + s_gr_dic) / REMIN_D_C_O2 +
-              (2.0 * NITRIF));
-    TEND(P.ind[0], ix) = t_po4;
-    TEND(P.ind[1], ix) = t_no3;
-    TEND(P.ind[2], ix) = t_sio3;
-    TEND(P.ind[3], ix) = t_nh4;
-    TEND(P.ind[4], ix) = t_fe;
-    TEND(P.ind[5], ix) = O2_PRODUCTION - O2_CONSUMPTION;
-    TEND(P.ind[6], ix) = t_dic;
-    TEND(P.ind[7], ix) = A.alt_co2_use_eco ? t_dic : 0.0;
-    TEND(P.ind[8], ix) = t_alk;
-    TEND(P.ind[9], ix) = t_doc;
-    TEND(P.ind[10], ix) = t_don;
-    TEND(P.ind[11], ix) = t_dofe;
-    TEND(P.ind[12], ix) = t_dop;
-    TEND(P.ind[13], ix) = t_dopr;
-    TEND(P.ind[14], ix) = t_donr;
-    TEND(P.ind[15], ix) = t_zooC;
-
-    // ---- diagnostics and column integrals (1796-1945) ----
-    if (DIAG) {
-      ST_KC(NO3_RESTORE, RESTORE); ST_KC(SiO3_RESTORE, RESTORE); ST_KC(PO4_RESTORE, RESTORE);
-      ST_KC(NITRIF, NITRIF); ST_KC(DENITRIF, DENITRIF);
-      ST_KC(O2_PRODUCTION, O2_PRODUCTION); ST_KC(O2_CONSUMPTION, O2_CONSUMPTION);
-      if (D.AOU) D.AOU[ix] = o2sat(T, S, T0K) - O2;
-      ST_KC(PAR_avg, PAR_avg); ST_KC(zoo_loss, zoo_loss); ST_KC(auto_graze_TOT, sum4(graze));
-      const double pCtot = sum4(photoC);
-      ST_KC(photoC_TOT, pCtot);
-      z_pCTot = z_pCTot + pCtot * dz;
-      double d_pCNO3 = 0.0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        ST_KCA(auto_graze, a, graze[a]); ST_KCA(auto_loss, a, loss[a]); ST_KCA(auto_agg, a, agg[a]);
-        ST_KCA(photoC, a, photoC[a]); ST_KCA(photoC_NO3, a, pC_NO3[a]);
-        z_pC[a] = z_pC[a] + dz * photoC[a];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        d_pCNO3 = d_pCNO3 + pC_NO3[a];
-        z_pCNO3[a] = z_pCNO3[a] + pC_NO3[a] * dz;
-        z_pCNO3Tot = z_pCNO3Tot + z_pCNO3[a];   // adds the RUNNING integral (1844-1846)
-      }
-      ST_KC(photoC_NO3_TOT, d_pCNO3);
-      ST_KC(DOC_prod, DOC_prod); ST_KC(DOC_remin, DOC_remin); ST_KC(DON_prod, DON_prod); ST_KC(DON_remin, DON_remin);
-      ST_KC(DOP_prod, DOP_prod); ST_KC(DOP_remin, DOP_remin); ST_KC(DOFe_prod, DOFe_prod); ST_KC(DOFe_remin, DOFe_remin);
+      ST_KC(DENITRIF, DENITRIF); ST_KC(O2_CONSUMPTION, O2_CONSUMPTION);
       ST_KC(Fe_scavenge, Fe_scavenge); ST_KC(Fe_scavenge_rate, Fe_scav_rate);
-      // conservation integrals
-      w2 = dmin(100.0e2 - zbot_above, dz);
+      // conservation integrals (1870-1938): local parts from the cell kernel + the tendencies finished here
+      const double w2 = dmin(100.0e2 - zbot_above, dz);
       const double pt100 = (w2 > 0.0) ? w2 : 0.0;
       const bool shallow = zb <= 100.0e2;
-      const double sC = ((t_C[0] + t_C[1]) + t_C[2]) + t_C[3];
-      w1 = t_dic + t_doc + t_zooC + sC;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (at[a].CaCO3_ind > 0) w1 = w1 + t_Ca[a];
+      w1 = t_dic + cur.jc;
       J_C = J_C + w1 * dz + sedPOC + sedCa;
       J_C100 = J_C100 + w1 * pt100 + (shallow ? sedPOC + sedCa : 0.0);
-      w1 = t_no3 + t_nh4 + t_don + t_donr + QN * t_zooC + QN * sC;
+      w1 = t_no3 + t_nh4 + t_donr + cur.jn;
       w1 = w1 + DENITRIF + SED_DENITRIF;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (at[a].Nfixer) w1 = w1 - Nfix[a];
       J_N = J_N + w1 * dz + sedPOC * QN;
       J_N100 = J_N100 + w1 * pt100 + (shallow ? sedPOC * QN : 0.0);
-      w1 = t_po4 + t_dop + t_dopr + QP_ZOO_POM * t_zooC;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) w1 = w1 + at[a].Qp * t_C[a];
+      w1 = t_po4 + t_dopr + cur.jp;
       J_P = J_P + w1 * dz + sedPOC * QP_ZOO_POM;
       J_P100 = J_P100 + w1 * pt100 + (shallow ? sedPOC * QP_ZOO_POM : 0.0);
-      w1 = t_sio3;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (at[a].Si_ind > 0) w1 = w1 + t_Si[a];
+      w1 = t_sio3 + cur.jsi;
       J_Si = J_Si + w1 * dz + sedSi;
       J_Si100 = J_Si100 + w1 * pt100 + (shallow ? sedSi : 0.0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) z_Chl100 = z_Chl100 + aChl[a] * pt100;
     }
     zbot_above = zb;
+    cur = nxt;
   }   // k
 
-  // ---- below the sea floor: the reference zero-fills tendencies and diagnostics (570, 625-727) ----
-  for (int k = (kmax > 0 ? kmax : 0); k < g.nlev; ++k) {
-    const long long ix = g.at(k, c);
-#pragma unroll 6
-    for (int n = 0; n < OBGC_BGC_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
-    if (DIAG) {
-#define ZKC(n) if (D.n) D.n[ix] = 0.0;
-      ZKC(tot_Nfix) ZKC(O2_PRODUCTION) ZKC(O2_CONSUMPTION) ZKC(AOU) ZKC(PO4_RESTORE) ZKC(NO3_RESTORE) ZKC(SiO3_RESTORE)
-      ZKC(PAR_avg) ZKC(POC_FLUX_IN) ZKC(POC_PROD) ZKC(POC_REMIN) ZKC(CaCO3_FLUX_IN) ZKC(CaCO3_PROD) ZKC(CaCO3_REMIN)
-      ZKC(SiO2_FLUX_IN) ZKC(SiO2_PROD) ZKC(SiO2_REMIN) ZKC(dust_FLUX_IN) ZKC(dust_REMIN) ZKC(P_iron_FLUX_IN)
-      ZKC(P_iron_PROD) ZKC(P_iron_REMIN) ZKC(auto_graze_TOT) ZKC(zoo_loss) ZKC(photoC_TOT) ZKC(photoC_NO3_TOT)
-      ZKC(DOC_prod) ZKC(DOC_remin) ZKC(DON_prod) ZKC(DON_remin) ZKC(DOFe_prod) ZKC(DOFe_remin) ZKC(DOP_prod)
-      ZKC(DOP_remin) ZKC(Fe_scavenge) ZKC(Fe_scavenge_rate) ZKC(NITRIF) ZKC(DENITRIF) ZKC(calcToSed) ZKC(pocToSed)
-      ZKC(ponToSed) ZKC(popToSed) ZKC(bsiToSed) ZKC(dustToSed) ZKC(pfeToSed) ZKC(SedDenitrif) ZKC(OtherRemin)
-      ZKC(tot_CaCO3_form)
-#undef ZKC
-#define ZKCA(n) if (D.n) { D.n[ix] = 0.0; D.n[pl + ix] = 0.0; D.n[2 * pl + ix] = 0.0; D.n[3 * pl + ix] = 0.0; }
-      ZKCA(N_lim) ZKCA(P_lim) ZKCA(Fe_lim) ZKCA(SiO3_lim) ZKCA(light_lim) ZKCA(photoC) ZKCA(photoC_NO3) ZKCA(photoFe)
-      ZKCA(photoNO3) ZKCA(photoNH4) ZKCA(DOP_uptake) ZKCA(PO4_uptake) ZKCA(auto_graze) ZKCA(auto_loss) ZKCA(auto_agg)
-      ZKCA(bSi_form) ZKCA(CaCO3_form) ZKCA(Nfix)
-#undef ZKCA
-    }
-  }
-
   if (DIAG) {
-    ST_C(O2_ZMIN, o2min); ST_C(O2_ZMIN_DEPTH, o2min_z);
-    ST_C(tot_bSi_form, z_bSi); ST_C(tot_CaCO3_form_zint, z_CaTot); ST_C(photoC_TOT_zint, z_pCTot);
-    ST_C(photoC_NO3_TOT_zint, z_pCNO3Tot); ST_C(Chl_TOT_zint_100m, z_Chl100);
     ST_C(Jint_Ctot, J_C); ST_C(Jint_100m_Ctot, J_C100); ST_C(Jint_Ntot, J_N); ST_C(Jint_100m_Ntot, J_N100);
     ST_C(Jint_Ptot, J_P); ST_C(Jint_100m_Ptot, J_P100); ST_C(Jint_Sitot, J_Si); ST_C(Jint_100m_Sitot, J_Si100);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      ST_CA(CaCO3_form_zint, a, z_Ca[a]); ST_CA(photoC_zint, a, z_pC[a]); ST_CA(photoC_NO3_zint, a, z_pCNO3[a]);
-    }
   }
-#undef TRC
 #undef TEND
 #undef ST_KC
-#undef ST_KCA
 #undef ST_C
-#undef ST_CA
+}
+
+// ---------------------------------------------------------------- column integrals (diagnostics only)
+// Vertical integrals of the production profiles, chlorophyll over the top 100 m and the O2 minimum
+// (BGC_mod.F90:1230, 1273-1277, 1816-1846, 1940-1945, 1954-1968).  None of them feeds or needs the particle
+// recurrence, so they run beside the sweep on another stream.  Sums keep the reference's top-down order.
+__global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  const GridView& g = A.g;
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if (c >= g.ncol) return;
+  const obgc_bgc_diag& D = A.diag;
+  const obgc_autotroph* at = P.autotrophs;
+  const long long pl = g.plane;
+  int kmax = A.kmax[c];
+  if (kmax > g.nlev) kmax = g.nlev;
+  double z_bSi = 0.0, z_CaTot = 0.0, z_pCTot = 0.0, z_pCNO3Tot = 0.0, z_Chl100 = 0.0;
+  double z_Ca[4] = {0, 0, 0, 0}, z_pC[4] = {0, 0, 0, 0}, z_pCNO3[4] = {0, 0, 0, 0};
+  double o2min = 0.0, o2min_z = 0.0;
+  const double* chl100 = A.scratch + (long long)S_CHL100 * A.splane;
+  const double* o2p = A.tracers + (long long)(P.ind[5] - 1) * pl;
+#pragma unroll 2
+  for (int k = 0; k < kmax; ++k) {
+    const long long ix = g.at(k, c);
+    const double dz = A.dz[ix];
+    const double O2 = dmax(0.0, o2p[ix]);
+    if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = A.zmid[ix]; }
+    double pC[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      pC[a] = A.z_photoC[(long long)a * pl + ix];
+      z_pC[a] = z_pC[a] + dz * pC[a];
+      if (at[a].Si_ind > 0) z_bSi = z_bSi + A.z_bSi_form[(long long)a * pl + ix];
+      if (at[a].imp_calcifier) {
+        const double w = dz * A.z_CaCO3_form[(long long)a * pl + ix];
+        z_Ca[a] = z_Ca[a] + w;
+        z_CaTot = z_CaTot + w;
+      }
+    }
+    z_pCTot = z_pCTot + sum4(pC) * dz;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      z_pCNO3[a] = z_pCNO3[a] + A.z_photoC_NO3[(long long)a * pl + ix] * dz;
+      z_pCNO3Tot = z_pCNO3Tot + z_pCNO3[a];   // adds the RUNNING integral (1844-1846)
+    }
+    z_Chl100 = z_Chl100 + chl100[ix];
+  }
+  if (D.O2_ZMIN) D.O2_ZMIN[c] = o2min;
+  if (D.O2_ZMIN_DEPTH) D.O2_ZMIN_DEPTH[c] = o2min_z;
+  if (D.tot_bSi_form) D.tot_bSi_form[c] = z_bSi;
+  if (D.tot_CaCO3_form_zint) D.tot_CaCO3_form_zint[c] = z_CaTot;
+  if (D.photoC_TOT_zint) D.photoC_TOT_zint[c] = z_pCTot;
+  if (D.photoC_NO3_TOT_zint) D.photoC_NO3_TOT_zint[c] = z_pCNO3Tot;
+  if (D.Chl_TOT_zint_100m) D.Chl_TOT_zint_100m[c] = z_Chl100;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (D.CaCO3_form_zint) D.CaCO3_form_zint[(long long)a * g.ldc + c] = z_Ca[a];
+    if (D.photoC_zint) D.photoC_zint[(long long)a * g.ldc + c] = z_pC[a];
+    if (D.photoC_NO3_zint) D.photoC_NO3_zint[(long long)a * g.ldc + c] = z_pCNO3[a];
+  }
 }
 
 }  // namespace
 
-void launch_bgc_ecosys(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
+void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1) {
   if (a.g.ncol <= 0) return;
-  const unsigned grid = (unsigned)((a.g.ncol + kBlock - 1) / kBlock);
-  if (a.have_diag) hipLaunchKernelGGL(bgc_ecosys_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a, p);
-  else hipLaunchKernelGGL(bgc_ecosys_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a, p);
+  const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
+  const long long ncell = (long long)a.g.nlev * a.g.ncol;
+  const unsigned gcell = (unsigned)((ncell + kBlockCell - 1) / kBlockCell);
+  hipLaunchKernelGGL(bgc_att_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, p);
+  hipLaunchKernelGGL(bgc_parscan_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a);
+  if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
+  if (a.have_diag) hipLaunchKernelGGL(bgc_cell_kernel<true>, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  else hipLaunchKernelGGL(bgc_cell_kernel<false>, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
+}
+
+void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
+  if (a.g.ncol <= 0 || !a.have_diag) return;
+  const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
+  hipLaunchKernelGGL(bgc_zint_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+}
+
+void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
+  if (a.g.ncol <= 0) return;
+  const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
+  if (a.have_diag) hipLaunchKernelGGL(bgc_sweep_kernel<true>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+  else hipLaunchKernelGGL(bgc_sweep_kernel<false>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
 }
 
 }  // namespace obgc

@@ -30,6 +30,19 @@ inline GridView make_view(const obgc_grid& g) {
   return v;
 }
 
+// Hand-off between the cell-parallel ecosystem kernel and the column sweep: one fp64 plane per
+// slot, laid out exactly like the caller's (k,column) arrays (same index, plane stride splane).
+enum ScratchSlot {
+  S_PARIN, S_ATT, S_KPARDZ,                    // PAR entering the level, exp(-KPARdz), KPARdz (att / scan kernels -> cell kernel)
+  S_PRODPOC, S_PRODCA, S_PRODSI, S_PFELOC,     // particle production terms (P_iron without scavenging)
+  S_DEC_POC, S_DEC_SIO2, S_DEC_CACO3, S_DEC_DUST, S_DEC_HARD, S_DEC_HARDDUST,   // decay factors across the level
+  S_POC_DISS, S_SIO2_DISS, S_CACO3_DISS,       // dissolution length scales
+  S_DOC_REMIN, S_NITRIF, S_ZLD, S_LSDIC, S_GRDIC, S_NEXC, S_CAX, S_CAPROD,       // pieces of the 11 coupled tendencies
+  S_NBASE,
+  S_JC = S_NBASE, S_JN, S_JP, S_JSI, S_CHL100, // diagnostics only: local parts of the column integrals
+  S_NDIAG
+};
+
 // ---------------------------------------------------------------- kernel arguments
 struct BgcKernelArgs {
   GridView g;
@@ -42,6 +55,11 @@ struct BgcKernelArgs {
   // carbonate results needed by the saturation-horizon scan when the caller did not ask
   // for the corresponding diagnostics (scratch owned by the handle, same shape as (k,c))
   double *co3_out, *sat_calc_out, *sat_arag_out;
+  // ecosystem hand-off scratch (ScratchSlot planes) and the four production profiles the sweep
+  // integrates vertically: the caller's diagnostic arrays when given, else scratch (4 planes each)
+  double* scratch;
+  long long splane;
+  double *z_photoC, *z_photoC_NO3, *z_CaCO3_form, *z_bSi_form;
   obgc_bgc_diag diag;
   int have_diag;
   int alt_co2_use_eco;
@@ -87,7 +105,9 @@ struct MacrosKernelArgs {
 // ---------------------------------------------------------------- launchers (one per .hip file)
 void launch_bgc_carbonate(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_zsat(const BgcKernelArgs& a, hipStream_t s);
-void launch_bgc_ecosys(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1);
+void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_surface(const SurfKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
 void launch_dms_surface(const DmsSurfKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
