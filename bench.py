@@ -164,13 +164,25 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    # rehearsal on a 1-GPU box: OBGC_BENCH_SHARE_GPU=1 maps every rank onto GPU 0 and uses gloo for the
+    # barrier / max-reduce (RCCL refuses two ranks on one device); the timed path is otherwise identical
+    share = os.environ.get("OBGC_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    red_dev = dev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            red_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ncol, nz, modules = CONFIGS[args.config]
     if args.columns:
@@ -278,7 +290,7 @@ def main():
             rezero()                      # keeps every timed step cold; 2 small memsets per 8 steps, inside the timing
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, updates_all = reduce_results(dist, elapsed, updates_per_step, dev)
+    elapsed, updates_all = reduce_results(dist, elapsed, updates_per_step, red_dev)
     value = updates_all * args.steps / elapsed
 
     if rank == 0:
