@@ -21,6 +21,8 @@ struct obgc_handle {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
              ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool timed_valid = false, tr_valid = false, cell_valid = false;
+  int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
+  int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides
   int sched = 0;   // experiment knob OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel
   obgc_bgc_params bgc;
   obgc_dms_params dms;
@@ -289,6 +291,8 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   for (auto e : evs)
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_KFAST_TILE")) { const int t = std::atoi(e); if (t >= 64) h->kfast_tile = t; }
   obgc_bgc_params_init(&h->bgc, nullptr, 273.15);
   obgc_dms_params_init(&h->dms, nullptr);
   obgc_macros_params_init(&h->macros, nullptr);
@@ -359,6 +363,88 @@ extern "C" double obgc_last_kernel_ms(obgc_handle* h, int which) {
   return e == hipSuccess ? (double)ms : -1.0;
 }
 
+
+namespace {
+
+
+// bytes of engine scratch obgc_bgc_source_sink needs for the view the kernels run on
+size_t bgc_scratch_bytes(const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat, bool workspace_has_all) {
+  const size_t kc1 = span_kc(kv, 1);
+  size_t bytes = 0;
+  if (want_zsat) {
+    if (!diag->CO3) bytes += align_up(kc1);
+    if (!diag->co3_sat_calc) bytes += align_up(kc1);
+    if (!diag->co3_sat_arag) bytes += align_up(kc1);
+  }
+  const long long span1 = (long long)(kc1 / sizeof(double));
+  const long long splane = (span1 + 31) & ~31LL;
+  const int nslots = diag ? (int)S_NDIAG : (int)S_NBASE;
+  bytes += align_up((size_t)nslots * splane * sizeof(double));
+  if (diag) {
+    const size_t zbytes = align_up((size_t)(3 * kv.plane + span1) * sizeof(double));
+    const int nfb = (diag->photoC ? 0 : 1) + (diag->photoC_NO3 ? 0 : 1) + (diag->CaCO3_form ? 0 : 1) + (diag->bSi_form ? 0 : 1);
+    bytes += nfb * zbytes;
+  }
+  (void)workspace_has_all;
+  return bytes;
+}
+
+// carve the scratch of one launch set out of the (already reserved) arena and hook it into K
+void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
+  const GridView& kv = K.g;
+  const size_t kc1 = span_kc(kv, 1);
+  auto carve = [&](size_t bytes) -> double* {
+    double* p = (double*)(h->arena + h->arena_used);
+    h->arena_used += align_up(bytes);
+    return p;
+  };
+  if (want_zsat) {
+    K.co3_out = K.diag.CO3 ? K.diag.CO3 : carve(kc1);
+    K.sat_calc_out = K.diag.co3_sat_calc ? K.diag.co3_sat_calc : carve(kc1);
+    K.sat_arag_out = K.diag.co3_sat_arag ? K.diag.co3_sat_arag : carve(kc1);
+  }
+  const long long span1 = (long long)(kc1 / sizeof(double));
+  const long long splane = (span1 + 31) & ~31LL;
+  const int nslots = K.have_diag ? (int)S_NDIAG : (int)S_NBASE;
+  K.scratch = carve((size_t)nslots * splane * sizeof(double));
+  K.splane = splane;
+  if (K.have_diag) {
+    const size_t zbytes = (size_t)(3 * kv.plane + span1) * sizeof(double);
+    K.z_photoC = K.diag.photoC ? K.diag.photoC : carve(zbytes);
+    K.z_photoC_NO3 = K.diag.photoC_NO3 ? K.diag.photoC_NO3 : carve(zbytes);
+    K.z_CaCO3_form = K.diag.CaCO3_form ? K.diag.CaCO3_form : carve(zbytes);
+    K.z_bSi_form = K.diag.bSi_form ? K.diag.bSi_form : carve(zbytes);
+  }
+}
+
+// s_main: attenuation -> PAR scan -> cell kernel -> particle sweep.
+// s_aux : carbonate cells -> saturation-horizon scan -> column integrals.
+// The device is saturated by the sum of these kernels: releasing the carbonate kernel at t = 0 or when the
+// cell kernel ends gives the same step time within 2 % (OBGC_SCHED=1 selects the latter for experiments).
+int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1);
+  h->cell_valid = true;
+  if (h->sched == 1) {
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
+  } else {
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_e0, 0));
+  }
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
+  launch_bgc_carbonate(K, h->bgc, h->s_aux);
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+  if (h->sched != 1) HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));   // zint reads the cell kernel's profiles
+  if (want_zsat) launch_bgc_zsat(K, h->s_aux);
+  launch_bgc_zint(K, h->bgc, h->s_aux);
+  HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
+  launch_bgc_ecosys_sweep(K, h->bgc, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
+  return OBGC_OK;
+}
+
+}  // namespace
+
 // ======================================================================== BGC_SourceSink ==
 
 extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_args* a) {
@@ -409,26 +495,32 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
     OBGC_BGC_DIAG_C(X)
 #undef X
   }
-  // scratch for the saturation-horizon scan when the caller did not ask for those profiles
   const bool want_zsat = a->diag && (a->diag->zsatcalc || a->diag->zsatarag);
-  size_t scratch = 0;
-  if (want_zsat) {
-    if (!a->diag->CO3) scratch += align_up(kc1);
-    if (!a->diag->co3_sat_calc) scratch += align_up(kc1);
-    if (!a->diag->co3_sat_arag) scratch += align_up(kc1);
+  // The reference layout is transposed through LDS tiles into a native workspace, one column tile at a
+  // time, so that every kernel runs on coalesced column-fastest rows (OBGC_KFAST_DIRECT=1 keeps the
+  // generic-stride path for A/B measurements).
+  const bool tiled = v.kfast && !h->kfast_direct;
+  const int tile_cols = tiled ? (v.ncol < h->kfast_tile ? v.ncol : h->kfast_tile) : v.ncol;
+  GridView kv = v;                       // the view the kernels see
+  if (tiled) {
+    kv.kfast = 0; kv.ncol = tile_cols; kv.sk = tile_cols; kv.sc = 1; kv.plane = (long long)tile_cols * v.nlev;
   }
-  // hand-off scratch of the ecosystem kernels, in the caller's index space
-  const long long span1 = (long long)(span_kc(v, 1) / sizeof(double));
-  const long long splane = (span1 + 31) & ~31LL;
-  const int nslots = a->diag ? (int)S_NDIAG : (int)S_NBASE;
-  scratch += align_up((size_t)nslots * splane * sizeof(double));
-  const size_t zbytes = align_up((size_t)(3 * v.plane + span1) * sizeof(double));
-  int nz_fallback = 0;
-  if (a->diag) {
-    nz_fallback = (a->diag->photoC ? 0 : 1) + (a->diag->photoC_NO3 ? 0 : 1) + (a->diag->CaCO3_form ? 0 : 1) + (a->diag->bSi_form ? 0 : 1);
-    scratch += nz_fallback * zbytes;
+  size_t work = 0;
+  const size_t tplane = (size_t)tile_cols * v.nlev * sizeof(double);
+  int n_kc_out = 0, n_kca_out = 0;
+  if (tiled) {
+    if (a->diag) {
+#define X(n) if (a->diag->n) ++n_kc_out;
+      OBGC_BGC_DIAG_KC(X)
+#undef X
+#define X(n) if (a->diag->n) ++n_kca_out;
+      OBGC_BGC_DIAG_KCA(X)
+#undef X
+    }
+    work = align_up(tplane * (size_t)(30 + 6 + 2 + 30 + n_kc_out + 4 * n_kca_out));
   }
-  int rc = arena_reserve(h, (st.host ? st.need : 0) + scratch);
+  const size_t scratch = bgc_scratch_bytes(kv, a->diag, want_zsat, tiled);
+  int rc = arena_reserve(h, (st.host ? st.need : 0) + work + scratch);
   if (rc != OBGC_OK) return rc;
   rc = stage_in(h, st);
   if (rc != OBGC_OK) return rc;
@@ -446,58 +538,72 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   K.diag = dd;
   K.have_diag = a->diag ? 1 : 0;
   K.alt_co2_use_eco = a->alt_co2_use_eco;
-  if (want_zsat) {
-    auto carve = [&](double* have) -> double* {
-      if (have) return have;
-      double* p = (double*)(h->arena + h->arena_used);
-      h->arena_used += align_up(kc1);
-      return p;
-    };
-    K.co3_out = carve(dd.CO3);
-    K.sat_calc_out = carve(dd.co3_sat_calc);
-    K.sat_arag_out = carve(dd.co3_sat_arag);
-  }
 
-  {
-    auto carve_bytes = [&](size_t bytes) -> double* {
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  if (!tiled) {
+    bgc_carve_scratch(h, K, want_zsat);
+    rc = bgc_launch(h, K, want_zsat);
+    if (rc != OBGC_OK) return rc;
+  } else {
+    // ---- native workspace (dense, column-fastest) ----
+    auto carve = [&](size_t bytes) -> double* {
       double* p = (double*)(h->arena + h->arena_used);
       h->arena_used += align_up(bytes);
       return p;
     };
-    K.scratch = carve_bytes((size_t)nslots * splane * sizeof(double));
-    K.splane = splane;
+    double* w = carve(work);
+    auto take = [&](int nplanes) -> double* { double* p = w; w += (tplane / sizeof(double)) * nplanes; return p; };
+    double* w_tr = take(30);
+    double *w_T = take(1), *w_S = take(1), *w_zm = take(1), *w_dz = take(1), *w_zb = take(1), *w_fs = take(1);
+    double *w_pp = take(1), *w_pa = take(1), *w_td = take(30);
+    BgcKernelArgs T = K;
+    T.g = kv;
+    T.tracers = w_tr; T.temp = w_T; T.salt = w_S; T.zmid = w_zm; T.dz = w_dz; T.zbot = w_zb; T.fesed = w_fs;
+    T.tend = w_td; T.ph_prev = w_pp; T.ph_prev_alt = w_pa;
+    struct Out { double* caller; double* ws; int planes; };
+    std::vector<Out> outs;
+    outs.push_back({K.tend, w_td, 30});
+    outs.push_back({K.ph_prev, w_pp, 1});
+    outs.push_back({K.ph_prev_alt, w_pa, 1});
     if (a->diag) {
-      K.z_photoC = dd.photoC ? dd.photoC : carve_bytes(zbytes);
-      K.z_photoC_NO3 = dd.photoC_NO3 ? dd.photoC_NO3 : carve_bytes(zbytes);
-      K.z_CaCO3_form = dd.CaCO3_form ? dd.CaCO3_form : carve_bytes(zbytes);
-      K.z_bSi_form = dd.bSi_form ? dd.bSi_form : carve_bytes(zbytes);
+#define X(n) if (dd.n) { T.diag.n = take(1); outs.push_back({dd.n, T.diag.n, 1}); }
+      OBGC_BGC_DIAG_KC(X)
+#undef X
+#define X(n) if (dd.n) { T.diag.n = take(4); outs.push_back({dd.n, T.diag.n, 4}); }
+      OBGC_BGC_DIAG_KCA(X)
+#undef X
+      // never written by the engine (nor by the reference): nothing to bring back
+      for (auto it = outs.begin(); it != outs.end();)
+        if (it->caller == dd.POC_ACCUM || it->caller == dd.DONr_remin || it->caller == dd.DOPr_remin) it = outs.erase(it);
+        else ++it;
     }
+    bgc_carve_scratch(h, T, want_zsat);
+    const size_t arena_mark = h->arena_used;
+    (void)arena_mark;
+    HIP_TRY(h, hipEventRecord(h->ev_t0, h->s_main));
+    for (int c0 = 0; c0 < v.ncol; c0 += tile_cols) {
+      const int nc = (v.ncol - c0 < tile_cols) ? (v.ncol - c0) : tile_cols;
+      BgcKernelArgs Tt = T;
+      Tt.g.ncol = nc;                      // a short last tile keeps the workspace strides of a full one
+      Tt.lat = K.lat + c0; Tt.kmax = K.kmax + c0; Tt.dust = K.dust + c0; Tt.sw = K.sw + c0;
+#define X(n) if (dd.n) Tt.diag.n = dd.n + c0;
+      OBGC_BGC_DIAG_CA(X)
+      OBGC_BGC_DIAG_C(X)
+#undef X
+      const long long off = (long long)c0 * v.sc;
+      const long long wl = kv.sk, wp = kv.plane;
+      launch_transpose_k2c(K.tracers + off, w_tr, v.nlev, nc, v.sc, v.plane, wl, wp, 30, h->s_main);
+      const double* ins[8] = {K.temp, K.salt, K.zmid, K.dz, K.zbot, K.fesed, K.ph_prev, K.ph_prev_alt};
+      double* wins[8] = {w_T, w_S, w_zm, w_dz, w_zb, w_fs, w_pp, w_pa};
+      for (int i = 0; i < 8; ++i) launch_transpose_k2c(ins[i] + off, wins[i], v.nlev, nc, v.sc, 0, wl, 0, 1, h->s_main);
+      if (c0 == 0) HIP_TRY(h, hipEventRecord(h->ev_t1, h->s_main));
+      rc = bgc_launch(h, Tt, want_zsat);
+      if (rc != OBGC_OK) return rc;
+      for (const Out& o : outs)
+        launch_transpose_c2k(o.ws, o.caller + off, v.nlev, nc, wl, wp, v.sc, v.plane, o.planes, h->s_main);
+    }
+    h->tr_valid = true;
   }
-
-  // ---- launch: carbonate cells on s_aux beside the ecosystem kernels on s_main ----
-  // s_main: attenuation -> PAR scan -> cell kernel -> particle sweep.
-  // s_aux : carbonate cells -> saturation-horizon scan, released when the cell kernel is done so that the
-  //         compute-bound carbonate wavefronts fill the SIMDs the latency-bound sweep (1.5 waves per SIMD at
-  //         100k columns) leaves idle, instead of competing with the bandwidth-bound cell kernel.
-  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
-  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
-  launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1);
-  h->cell_valid = true;
-  if (h->sched == 1) {
-    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
-  } else {
-    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_begin, 0));
-  }
-  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
-  launch_bgc_carbonate(K, h->bgc, h->s_aux);
-  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
-  if (h->sched != 1) HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));   // zint reads the cell kernel's profiles
-  if (want_zsat) launch_bgc_zsat(K, h->s_aux);
-  launch_bgc_zint(K, h->bgc, h->s_aux);     // column integrals of the cell kernel's profiles (diagnostics only)
-  HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
-  launch_bgc_ecosys_sweep(K, h->bgc, h->s_main);
-  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
-  HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
   HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
   HIP_TRY(h, hipGetLastError());
   h->timed_valid = true;

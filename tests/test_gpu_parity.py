@@ -174,3 +174,28 @@ def test_device_generator_is_bit_identical_to_numpy(pkg, synth):
     got = tr.cpu().numpy().transpose(0, 2, 1)
     for i, nm in enumerate(synth.BGC_TRACERS):
         assert np.array_equal(got[i], ref[i]), nm
+
+
+def test_reference_layout_tiled_transposes(pkg, oracle, synth, monkeypatch):
+    """Reference-layout callers go through LDS-tiled transposes in column tiles: force several tiles
+    (incl. a short last one) and require the same bits as the native-layout path."""
+    from ocean_bgc_amd.modules import ColumnEngine
+    monkeypatch.setenv("OBGC_KFAST_TILE", "704")
+    Ek = ColumnEngine(0, path="device_kfast")
+    Eh = ColumnEngine(0, path="host")
+    monkeypatch.delenv("OBGC_KFAST_TILE")
+    Ec = ColumnEngine(0, path="device_colfast")
+    nc, nz = 2000, 60
+    syn = synth.generate(nc, nz, col0=5150)
+    tr = synth.bgc_tracer_array(syn)
+    args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"],
+            syn["dust"], syn["sw"])
+    z = np.zeros((nc, nz))
+    a, b, c = Ek.BGC_SourceSink(*args, z, z, diag_init=-7.0), Ec.BGC_SourceSink(*args, z, z, diag_init=-7.0), \
+        Eh.BGC_SourceSink(*args, z, z, diag_init=-7.0)
+    for other in (a, c):
+        assert np.array_equal(other["tend"], b["tend"]) and np.array_equal(other["ph_prev"], b["ph_prev"])
+        for grp in ("kc", "kca", "ca", "c"):
+            for nm in b[grp]:
+                assert np.array_equal(other[grp][nm], b[grp][nm]), (grp, nm)
+    _assert(P.compare_bgc(a, oracle.bgc_source_sink(*args, z, z, diag_init=-7.0)), "tiled reference layout")
