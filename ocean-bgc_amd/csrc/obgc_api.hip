@@ -21,6 +21,7 @@ struct obgc_handle {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
              ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool timed_valid = false, tr_valid = false, cell_valid = false;
+  int sweep_lanes = 0;    // experiment knob OBGC_SWEEP_LANES: 16 / 32 / 64 active lanes per wavefront in the sweep, 0 = auto
   int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
   int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides
   int sched = 0;   // experiment knob OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel
@@ -292,6 +293,7 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_TILE")) { const int t = std::atoi(e); if (t >= 64) h->kfast_tile = t; }
   obgc_bgc_params_init(&h->bgc, nullptr, 273.15);
   obgc_dms_params_init(&h->dms, nullptr);
@@ -437,7 +439,7 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   if (want_zsat) launch_bgc_zsat(K, h->s_aux);
   launch_bgc_zint(K, h->bgc, h->s_aux);
   HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
-  launch_bgc_ecosys_sweep(K, h->bgc, h->s_main);
+  launch_bgc_ecosys_sweep(K, h->bgc, h->s_main, h->sweep_lanes);
   HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
   return OBGC_OK;

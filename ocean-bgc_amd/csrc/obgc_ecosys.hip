@@ -595,10 +595,12 @@ __device__ __forceinline__ void load_level(const BgcKernelArgs& A, const obgc_bg
 #undef SCR
 }
 
-template <bool DIAG>
+// LANES = active lanes per wavefront (experiment knob, see launch_bgc_ecosys_sweep; 64 is the default).
+template <bool DIAG, int LANES>
 __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
   const GridView& g = A.g;
-  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if ((int)threadIdx.x >= LANES) return;
+  const int c = blockIdx.x * LANES + threadIdx.x;
   if (c >= g.ncol) return;
   const obgc_bgc_diag& D = A.diag;
   const long long pl = g.plane;
@@ -860,11 +862,22 @@ void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream
   hipLaunchKernelGGL(bgc_zint_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
 }
 
-void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
+template <int LANES>
+static void launch_sweep_lanes(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
+  const unsigned grid = (unsigned)((a.g.ncol + LANES - 1) / LANES);
+  if (a.have_diag) hipLaunchKernelGGL((bgc_sweep_kernel<true, LANES>), dim3(grid), dim3(kBlockCol), 0, s, a, p);
+  else hipLaunchKernelGGL((bgc_sweep_kernel<false, LANES>), dim3(grid), dim3(kBlockCol), 0, s, a, p);
+}
+
+void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int lanes) {
   if (a.g.ncol <= 0) return;
-  const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
-  if (a.have_diag) hipLaunchKernelGGL(bgc_sweep_kernel<true>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
-  else hipLaunchKernelGGL(bgc_sweep_kernel<false>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+  // Measured on MI355X at 100k columns (OBGC_SWEEP_LANES): 64 lanes 4.87 ms/step, 32 lanes 5.04, 16 lanes 5.85 --
+  // partially filled wavefronts multiply the independent chains but waste memory-instruction issue, which is
+  // what binds the sweep; full wavefronts stay the default.
+  if (lanes <= 0) lanes = 64;
+  if (lanes >= 64) launch_sweep_lanes<64>(a, p, s);
+  else if (lanes >= 32) launch_sweep_lanes<32>(a, p, s);
+  else launch_sweep_lanes<16>(a, p, s);
 }
 
 }  // namespace obgc

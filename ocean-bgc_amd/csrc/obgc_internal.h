@@ -106,7 +106,7 @@ struct MacrosKernelArgs {
 void launch_bgc_carbonate(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_zsat(const BgcKernelArgs& a, hipStream_t s);
 void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1);
-void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int lanes);
 void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_surface(const SurfKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s);

@@ -199,3 +199,84 @@ def test_reference_layout_tiled_transposes(pkg, oracle, synth, monkeypatch):
             for nm in b[grp]:
                 assert np.array_equal(other[grp][nm], b[grp][nm]), (grp, nm)
     _assert(P.compare_bgc(a, oracle.bgc_source_sink(*args, z, z, diag_init=-7.0)), "tiled reference layout")
+
+
+@pytest.mark.parametrize("layout", ["colfast", "kfast"])
+def test_padded_strides_leave_the_padding_alone(pkg, synth, layout):
+    """Callers may pass arrays larger than the batch (ld > extent, plane > ld*extent; the reference's
+    numLevelsMax / numColumnsMax).  Results must equal the dense call bit for bit and the padding must
+    stay untouched."""
+    import torch
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    eng = Engine(0)
+    nc, nz = 1000, 37
+    syn = synth.generate(nc, nz, col0=77)
+    tr = synth.bgc_tracer_array(syn)
+    kc_names = ("temp", "salt", "zmid", "dz", "zbot", "fesed")
+    f64 = dict(dtype=torch.float64, device="cuda")
+    if layout == "colfast":
+        ld, rows = nc + 13, nz
+        lay = L.OBGC_LAYOUT_COLFAST
+        def dense(x): return np.ascontiguousarray(np.swapaxes(x, -1, -2))          # [.., nz, nc]
+    else:
+        ld, rows = nz + 3, nc
+        lay = L.OBGC_LAYOUT_KFAST
+        def dense(x): return np.ascontiguousarray(x)                                # [.., nc, nz]
+    plane = ld * (rows + 5) + 7
+    ldc = nc + 9
+
+    def padded(x, nplanes):
+        """-> (flat tensor with NaN padding, dense view into it)"""
+        d = torch.from_numpy(dense(x)).cuda()
+        flat = torch.full((nplanes * plane,), float("nan"), **f64)
+        view = torch.as_strided(flat, (nplanes, d.shape[-2], d.shape[-1]), (plane, ld, 1))
+        view.copy_(d.reshape(nplanes, d.shape[-2], d.shape[-1]))
+        return flat, view
+
+    def run(pad):
+        t = {}
+        if pad:
+            t["tr"], _ = padded(tr, 30)
+            for nm in kc_names:
+                t[nm], _ = padded(syn[nm][None], 1)
+            t["tend"], tv = padded(np.zeros_like(tr), 30)
+            t["php"], pv = padded(np.zeros((1, nc, nz)), 1)
+            t["pha"], av = padded(np.zeros((1, nc, nz)), 1)
+            t["lim"], lv = padded(np.zeros((4, nc, nz)), 4)
+            zint_flat = torch.full((4 * ldc,), float("nan"), **f64)
+            zint = torch.as_strided(zint_flat, (4, nc), (ldc, 1))
+            kw = dict(ld=ld, plane=plane, ldc=ldc)
+        else:
+            t["tr"] = torch.from_numpy(dense(tr)).cuda()
+            for nm in kc_names:
+                t[nm] = torch.from_numpy(dense(syn[nm])).cuda()
+            tv = t["tend"] = torch.zeros_like(t["tr"])
+            pv = t["php"] = torch.zeros_like(t["temp"]); av = t["pha"] = torch.zeros_like(t["temp"])
+            lv = t["lim"] = torch.zeros((4,) + tuple(t["temp"].shape), **f64)
+            zint_flat = zint = torch.zeros((4, nc), **f64)
+            kw = {}
+        c = {nm: torch.from_numpy(np.ascontiguousarray(syn[k])).cuda() for nm, k in (("lat", "lat"), ("dust", "dust"), ("sw", "sw"))}
+        km = torch.from_numpy(syn["kmax"]).cuda()
+        diag = {"N_lim": t["lim"], "photoC_zint": zint_flat, "Jint_Ctot": torch.zeros((nc,), **f64)}
+        torch.cuda.synchronize()
+        eng.bgc_source_sink(nz, nc, lay, t["tr"], t["temp"], t["salt"], t["zmid"], t["dz"], t["zbot"], c["lat"], km, t["fesed"],
+                            c["dust"], c["sw"], t["tend"], t["php"], t["pha"], diag, True, **kw)
+        return t, tv.clone(), pv.clone(), lv.clone(), zint.clone(), zint_flat
+
+    tp, tend_p, ph_p, lim_p, zint_p, zflat = run(True)
+    td, tend_d, ph_d, lim_d, zint_d, _ = run(False)
+    assert torch.equal(tend_p.reshape(tend_d.shape), tend_d)
+    assert torch.equal(ph_p.reshape(ph_d.shape), ph_d)
+    assert torch.equal(lim_p.reshape(lim_d.shape), lim_d)
+    assert torch.equal(zint_p, zint_d)
+    # padding: everything outside the strided views is still NaN
+    for key, npl in (("tend", 30), ("php", 1), ("lim", 4)):
+        flat = tp[key]
+        mask = torch.ones_like(flat, dtype=torch.bool)
+        view_mask = torch.as_strided(mask, (npl, tend_p.shape[-2] if key != "php" else ph_p.shape[-2], ph_p.shape[-1]), (plane, ld, 1))
+        view_mask.fill_(False)
+        assert torch.isnan(flat[mask]).all(), key
+    zmask = torch.ones_like(zflat, dtype=torch.bool)
+    torch.as_strided(zmask, (4, nc), (ldc, 1)).fill_(False)
+    assert torch.isnan(zflat[zmask]).all()
