@@ -24,7 +24,7 @@ struct obgc_handle {
   int sweep_lanes = 0;    // experiment knob OBGC_SWEEP_LANES: 16 / 32 / 64 active lanes per wavefront in the sweep, 0 = auto
   int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
   int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides
-  int sched = 0;   // experiment knob OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel
+  int sched = 1;   // OBGC_SCHED: 0 carbonate from the start, 1 (default) carbonate released after the cell kernel, 2 carbonate inside the cell kernel
   obgc_bgc_params bgc;
   obgc_dms_params dms;
   obgc_macros_params macros;
@@ -425,8 +425,20 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
 // cell kernel ends gives the same step time within 2 % (OBGC_SCHED=1 selects the latter for experiments).
 int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
-  launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1);
+  launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1, h->sched == 2);
   h->cell_valid = true;
+  if (h->sched == 2) {   // carbonate solved inside the cell kernel's wavefronts
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
+    HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
+    HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+    if (want_zsat) launch_bgc_zsat(K, h->s_aux);
+    launch_bgc_zint(K, h->bgc, h->s_aux);
+    HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
+    launch_bgc_ecosys_sweep(K, h->bgc, h->s_main, h->sweep_lanes);
+    HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
+    return OBGC_OK;
+  }
   if (h->sched == 1) {
     HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
   } else {

@@ -130,6 +130,7 @@ struct TalkInv {
   double bt_kb, sit_ksi;                  // bt*kb, sit*ksi
   double pt, pt_k12p, two_pt_k123p;       // pt, pt*k12p, (2*pt)*k123p
   double c_r, c_ks;                       // 1/(1+st/ks), (1+st/ks)*ks
+  double st_cks, ft_kf;                   // st*c_ks, ft*kf (single-division form only)
 };
 
 __device__ __forceinline__ void talk_setup(const Co3Consts& c, double dic, double ta, double pt, double sit, TalkInv& v) {
@@ -148,11 +149,15 @@ __device__ __forceinline__ void talk_setup(const Co3Consts& c, double dic, doubl
   const double cc = 1.0 + c.st / c.ks;
   v.c_r = 1.0 / cc;
   v.c_ks = cc * c.ks;
+  v.st_cks = c.st * v.c_ks;
+  v.ft_kf = c.ft * c.kf;
   (void)c.kw;
 }
 
-// alkalinity residual fn(x) and d fn / dx  (talk_row)
-__device__ __forceinline__ void talk_row(const TalkInv& v, double kw, double x1, double& fn, double& df) {
+// alkalinity residual fn(x) and d fn / dx, term by term in the reference's order (talk_row,
+// co2calc.F90:1036-1090): seven divisions per evaluation.  Kept as the documented contract and as a build
+// knob (-DOBGC_TALK_REFORDER) for A/B runs; the shipped solver uses talk_row below.
+__device__ __forceinline__ void talk_row_reforder(const TalkInv& v, double kw, double x1, double& fn, double& df) {
   const double x1_r = 1.0 / x1;
   const double x2 = x1 * x1;
   const double x2_r = x1_r * x1_r;
@@ -178,6 +183,74 @@ __device__ __forceinline__ void talk_row(const TalkInv& v, double kw, double x1,
        (v.pt_k12p * (a - x1 * da)) * a2_r - v.two_pt_k123p * da * a2_r - v.sit_ksi * ksi_p_x1_r * ksi_p_x1_r -
        1.0 * v.c_r - v.st * c1_p_c_ks_x1_r_r * c1_p_c_ks_x1_r_r * (v.c_ks * x2_r) -
        v.ft * c1_p_kf_x1_r_r * c1_p_kf_x1_r_r * v.kf * x2_r - v.pt * x2 * (3.0 * a - x1 * da) * a2_r;
+}
+
+// The same residual and derivative with ONE reciprocal per evaluation.  talk_row is 80 % of the carbonate
+// kernel's instructions (2 solves x ~13 evaluations per cell) and the kernel runs at 96 % of the fp64 issue
+// rate, so its instruction count IS its run time.  Identities used:
+//   1/(1 + c_ks/x) = x/(x + c_ks),  1/(1 + kf/x) = x/(x + kf)      (the two "free-scale" terms)
+//   the seven reciprocals 1/x, 1/a, 1/b, 1/(kb+x), 1/(ksi+x), 1/(x+c_ks), 1/(x+kf) come from one reciprocal
+//   of their product (|product| stays within 1e-90..1e-30 for 1e-13 < x < 1e-3) and 18 multiplications;
+//   sums are written with fma.
+// This leaves the reference's operation order: each term moves by a few ulp, the root by ~1e-15 relative
+// (Newton is self-correcting), far inside the pH bar of 1e-12; measured parity is quoted in DESIGN.md.
+__device__ __forceinline__ double rcp_nr(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  double e = __builtin_fma(-p, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-p, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+__device__ __forceinline__ void talk_row(const TalkInv& v, double kw, double x, double& fn, double& df) {
+#ifdef OBGC_TALK_REFORDER
+  talk_row_reforder(v, kw, x, fn, df);
+#else
+  const double x2 = x * x;
+  const double x3 = x2 * x;
+  const double a = __builtin_fma(__builtin_fma(x + v.k1p, x, v.k12p), x, v.k123p);
+  const double da = __builtin_fma(__builtin_fma(3.0, x, v.two_k1p), x, v.k12p);
+  const double b = __builtin_fma(x + v.k1, x, v.k12);
+  const double db = __builtin_fma(2.0, x, v.k1);
+  const double u = v.kb + x, w = v.ksi + x, s = x + v.c_ks, q = x + v.kf;
+  // batch inversion
+  const double p1 = x * a, p2 = p1 * b, p3 = p2 * u, p4 = p3 * w, p5 = p4 * s, p6 = p5 * q;
+  double r = rcp_nr(p6);
+  const double q_r = r * p5; r = r * q;
+  const double s_r = r * p4; r = r * s;
+  const double w_r = r * p3; r = r * w;
+  const double u_r = r * p2; r = r * u;
+  const double b_r = r * p1; r = r * b;
+  const double a_r = r * x;
+  const double x_r = r * a;
+
+  const double n_b = __builtin_fma(v.k1_dic, x, v.two_dic_k12);
+  const double n_a = __builtin_fma(-v.pt, x3, __builtin_fma(v.pt_k12p, x, v.two_pt_k123p));
+  double t = n_b * b_r;
+  t = __builtin_fma(v.bt_kb, u_r, t);
+  t = __builtin_fma(kw, x_r, t);
+  t = __builtin_fma(n_a, a_r, t);
+  t = __builtin_fma(v.sit_ksi, w_r, t);
+  t = __builtin_fma(-x, v.c_r, t);
+  t = __builtin_fma(-v.st, x * s_r, t);
+  t = __builtin_fma(-v.ft, x * q_r, t);
+  fn = t - v.ta;
+
+  const double xda = x * da;
+  double m_b = v.k1_dic * __builtin_fma(-x, db, b);
+  m_b = __builtin_fma(-v.two_dic_k12, db, m_b);
+  double m_a = v.pt_k12p * (a - xda);
+  m_a = __builtin_fma(-v.two_pt_k123p, da, m_a);
+  m_a = __builtin_fma(-(v.pt * x2), __builtin_fma(3.0, a, -xda), m_a);
+  double d = m_b * (b_r * b_r);
+  d = __builtin_fma(-v.bt_kb, u_r * u_r, d);
+  d = __builtin_fma(-kw, x_r * x_r, d);
+  d = __builtin_fma(m_a, a_r * a_r, d);
+  d = __builtin_fma(-v.sit_ksi, w_r * w_r, d);
+  d = d - v.c_r;
+  d = __builtin_fma(-v.st_cks, s_r * s_r, d);
+  df = __builtin_fma(-v.ft_kf, q_r * q_r, d);
+#endif
 }
 
 // Unit conversion + clamps of comp_htotal (co2calc.F90:836-846)
@@ -279,6 +352,126 @@ __device__ __forceinline__ void comp_co3_sat_vals(bool deep, double depth, doubl
   const double inv_Ca = (35.0 / 0.01028) / salt_lim;
   sat_calc = (K_calc * inv_Ca) * OBGC_MASS_TO_VOL;
   sat_arag = (K_arag * inv_Ca) * OBGC_MASS_TO_VOL;
+}
+
+// One cell of the interior carbonate block (BGC_mod.F90:935-1001): constants, the two [H+] solves, species,
+// saturation values, PH_PREV_* update.  Every lane of the wavefront must call it (the solver votes with
+// wavefront ballots); `inside` = the lane maps to a cell of the grid at all.
+__device__ __forceinline__ void carbonate_cell(const BgcKernelArgs& A, int i_dic, int i_alk, int i_po4, int i_sio3, bool inside,
+                                               int k, int c) {
+  const GridView& g = A.g;
+  const int kmax = inside ? A.kmax[c] : 0;
+  const bool live = inside && k < kmax;
+  const long long ix = inside ? g.at(k, c) : 0;
+
+  double T = 10.0, S = 35.0, depth = 0.0, dic = 2000.0, alk = 2300.0, po4 = 0.0, sio3 = 0.0;
+  double php = 0.0, pha = 0.0;
+  if (live) {
+    T = A.temp[ix];
+    S = A.salt[ix];
+    depth = A.zmid[ix] * 0.01;                                   // cm -> m, BGC_mod.F90:950
+    dic = dmax(0.0, A.tracers[(long long)(i_dic - 1) * g.plane + ix]);   // clamps of 747-752
+    alk = dmax(0.0, A.tracers[(long long)(i_alk - 1) * g.plane + ix]);
+    po4 = dmax(0.0, A.tracers[(long long)(i_po4 - 1) * g.plane + ix]);
+    sio3 = dmax(0.0, A.tracers[(long long)(i_sio3 - 1) * g.plane + ix]);
+    php = A.ph_prev[ix];
+    pha = A.ph_prev_alt[ix];
+  }
+  const bool deep = k > 0;   // reference level index k > 1
+  if (__ballot(live) == 0ull) {
+    // whole wavefront has nothing to solve (land / below the sea floor): only the zero fill
+    if (inside && A.have_diag) {
+      const obgc_bgc_diag& D = A.diag;
+      if (D.CO3) D.CO3[ix] = 0.0;
+      if (D.HCO3) D.HCO3[ix] = 0.0;
+      if (D.H2CO3) D.H2CO3[ix] = 0.0;
+      if (D.pH_3D) D.pH_3D[ix] = 0.0;
+      if (D.CO3_ALT_CO2) D.CO3_ALT_CO2[ix] = 0.0;
+      if (D.HCO3_ALT_CO2) D.HCO3_ALT_CO2[ix] = 0.0;
+      if (D.H2CO3_ALT_CO2) D.H2CO3_ALT_CO2[ix] = 0.0;
+      if (D.pH_3D_ALT_CO2) D.pH_3D_ALT_CO2[ix] = 0.0;
+      if (D.co3_sat_calc) D.co3_sat_calc[ix] = 0.0;
+      if (D.co3_sat_arag) D.co3_sat_arag[ix] = 0.0;
+    }
+    return;
+  }
+
+  Co3Consts cc;
+  double ff_unused;
+  comp_co3_coeffs<false>(deep, depth, T, S, cc, ff_unused);
+
+  // comp_htotal's clamps and conversion to mol/kg (co2calc.F90:843-846)
+  const double vol_to_mass = 1.0 / OBGC_MASS_TO_VOL;
+  const double dic_m = dmax(dic, OBGC_DIC_MIN) * vol_to_mass;
+  const double ta_m = dmax(alk, OBGC_ALK_MIN) * vol_to_mass;
+  const double pt_m = dmax(po4, 0.0) * vol_to_mass;
+  const double sit_m = dmax(sio3, 0.0) * vol_to_mass;
+  TalkInv tv;
+  talk_setup(cc, dic_m, ta_m, pt_m, sit_m, tv);
+
+  // brackets: previous pH +- del_ph, or [6, 9] when there is none (BGC_mod.F90:943-949, 965-971)
+  const double lo1 = (php != 0.0) ? php - 0.20 : 6.0, hi1 = (php != 0.0) ? php + 0.20 : 9.0;
+  const double lo2 = (pha != 0.0) ? pha - 0.20 : 6.0, hi2 = (pha != 0.0) ? pha + 0.20 : 9.0;
+
+  const double h1 = solve_htotal(live, tv, cc.kw, lo1, hi1);
+  double h2 = h1;
+  const bool differs = live && (lo2 != lo1 || hi2 != hi1);
+  if (__ballot(differs) != 0ull) {
+    const double h2s = solve_htotal(differs, tv, cc.kw, lo2, hi2);
+    if (differs) h2 = h2s;
+  }
+
+  double sat_calc, sat_arag;
+  comp_co3_sat_vals(deep, depth, T, S, sat_calc, sat_arag);
+
+  if (!inside) return;
+  if (live) {
+    // species from [H+] (co2calc.F90:301-314)
+    const double ph1 = -log10(h1);
+    const double ph2 = (h2 == h1) ? ph1 : -log10(h2);
+    A.ph_prev[ix] = ph1;
+    A.ph_prev_alt[ix] = ph2;
+    const double k12 = cc.k1 * cc.k2;
+    double hh = h1 * h1;
+    double denom = 1.0 / (hh + cc.k1 * h1 + k12);
+    const double H2CO3 = (dic_m * hh * denom) * OBGC_MASS_TO_VOL;
+    const double HCO3 = (dic_m * cc.k1 * h1 * denom) * OBGC_MASS_TO_VOL;
+    const double CO3 = (dic_m * cc.k1 * cc.k2 * denom) * OBGC_MASS_TO_VOL;
+    if (A.co3_out) A.co3_out[ix] = CO3;
+    if (A.sat_calc_out) A.sat_calc_out[ix] = sat_calc;
+    if (A.sat_arag_out) A.sat_arag_out[ix] = sat_arag;
+    if (A.have_diag) {
+      const obgc_bgc_diag& D = A.diag;
+      if (D.CO3 && D.CO3 != A.co3_out) D.CO3[ix] = CO3;   // may double as the zsat scan's input
+      if (D.HCO3) D.HCO3[ix] = HCO3;
+      if (D.H2CO3) D.H2CO3[ix] = H2CO3;
+      if (D.pH_3D) D.pH_3D[ix] = ph1;
+      if (D.co3_sat_calc && D.co3_sat_calc != A.sat_calc_out) D.co3_sat_calc[ix] = sat_calc;
+      if (D.co3_sat_arag && D.co3_sat_arag != A.sat_arag_out) D.co3_sat_arag[ix] = sat_arag;
+      if (D.CO3_ALT_CO2 || D.HCO3_ALT_CO2 || D.H2CO3_ALT_CO2) {
+        hh = h2 * h2;
+        denom = 1.0 / (hh + cc.k1 * h2 + k12);
+        if (D.H2CO3_ALT_CO2) D.H2CO3_ALT_CO2[ix] = (dic_m * hh * denom) * OBGC_MASS_TO_VOL;
+        if (D.HCO3_ALT_CO2) D.HCO3_ALT_CO2[ix] = (dic_m * cc.k1 * h2 * denom) * OBGC_MASS_TO_VOL;
+        if (D.CO3_ALT_CO2) D.CO3_ALT_CO2[ix] = (dic_m * cc.k1 * cc.k2 * denom) * OBGC_MASS_TO_VOL;
+      }
+      if (D.pH_3D_ALT_CO2) D.pH_3D_ALT_CO2[ix] = ph2;
+    }
+  } else if (A.have_diag) {
+    // the reference zero-fills every diagnostic first (BGC_mod.F90:649-658); PH_PREV_* of
+    // inactive cells are left untouched
+    const obgc_bgc_diag& D = A.diag;
+    if (D.CO3) D.CO3[ix] = 0.0;
+    if (D.HCO3) D.HCO3[ix] = 0.0;
+    if (D.H2CO3) D.H2CO3[ix] = 0.0;
+    if (D.pH_3D) D.pH_3D[ix] = 0.0;
+    if (D.CO3_ALT_CO2) D.CO3_ALT_CO2[ix] = 0.0;
+    if (D.HCO3_ALT_CO2) D.HCO3_ALT_CO2[ix] = 0.0;
+    if (D.H2CO3_ALT_CO2) D.H2CO3_ALT_CO2[ix] = 0.0;
+    if (D.pH_3D_ALT_CO2) D.pH_3D_ALT_CO2[ix] = 0.0;
+    if (D.co3_sat_calc) D.co3_sat_calc[ix] = 0.0;
+    if (D.co3_sat_arag) D.co3_sat_arag[ix] = 0.0;
+  }
 }
 
 }  // namespace obgc

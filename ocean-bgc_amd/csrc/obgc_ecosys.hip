@@ -27,7 +27,7 @@
 // re-associates (Fe, SiO3, PO4: the per-autotroph terms are folded before the particle terms
 // are added) and P_iron production (Fe scavenging added last); the change is a few ulp of the
 // largest term, far inside the parity bar, and is listed in DESIGN.md.
-#include "obgc_internal.h"
+#include "obgc_co2.h"
 
 namespace obgc {
 
@@ -77,21 +77,39 @@ __device__ __forceinline__ double o2sat(double SST, double SSS, double T0K) {
   return v / 0.0223916;
 }
 
+// Pins a wave-uniform parameter in an SGPR pair.  Without it the compiler turns  lane_cond ? param_a : param_b
+// into a per-lane VECTOR load from a selected address; inside the autotroph loop that load queues behind every
+// diagnostic store already issued (loads and stores retire in order) and stalls the wave for a memory round trip.
+__device__ __forceinline__ double uniform(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
 // Masked, clamped autotroph pools of one cell (BGC_mod.F90:764-785, 826-844)
 struct Pools { double Chl[4], C[4], Fe[4], Si[4], Ca[4]; };
 
-__device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_autotroph* at, long long ix, bool want_ca, Pools& p) {
+__device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_autotroph* at, long long ix, Pools& p) {
   const long long pl = A.g.plane;
+  // all loads first and unconditional (an autotroph without Si reads its C plane again and discards it): one
+  // wait for the whole batch instead of one memory round trip per uniform branch
+  double si[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    p.Chl[a] = dmax(0.0, A.tracers[(long long)(at[a].Chl_ind - 1) * pl + ix]);
-    p.C[a] = dmax(0.0, A.tracers[(long long)(at[a].C_ind - 1) * pl + ix]);
-    p.Fe[a] = dmax(0.0, A.tracers[(long long)(at[a].Fe_ind - 1) * pl + ix]);
-    p.Si[a] = (at[a].Si_ind > 0) ? dmax(0.0, A.tracers[(long long)(at[a].Si_ind - 1) * pl + ix]) : 0.0;
-    p.Ca[a] = (want_ca && at[a].CaCO3_ind > 0) ? dmax(0.0, A.tracers[(long long)(at[a].CaCO3_ind - 1) * pl + ix]) : 0.0;
+    p.Chl[a] = A.tracers[(long long)(at[a].Chl_ind - 1) * pl + ix];
+    p.C[a] = A.tracers[(long long)(at[a].C_ind - 1) * pl + ix];
+    p.Fe[a] = A.tracers[(long long)(at[a].Fe_ind - 1) * pl + ix];
+    si[a] = A.tracers[(long long)((at[a].Si_ind > 0 ? at[a].Si_ind : at[a].C_ind) - 1) * pl + ix];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    p.Chl[a] = dmax(0.0, p.Chl[a]);
+    p.C[a] = dmax(0.0, p.C[a]);
+    p.Fe[a] = dmax(0.0, p.Fe[a]);
+    p.Si[a] = (at[a].Si_ind > 0) ? dmax(0.0, si[a]) : 0.0;
+    p.Ca[a] = 0.0;
     bool empty = p.Chl[a] == 0.0 || p.C[a] == 0.0 || p.Fe[a] == 0.0;
     if (at[a].Si_ind > 0) empty = empty || p.Si[a] == 0.0;
-    if (empty) { p.Chl[a] = 0.0; p.C[a] = 0.0; p.Fe[a] = 0.0; p.Si[a] = 0.0; p.Ca[a] = 0.0; }
+    if (empty) { p.Chl[a] = 0.0; p.C[a] = 0.0; p.Fe[a] = 0.0; p.Si[a] = 0.0; }
   }
 }
 
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void bgc_att_kernel(const BgcKernelArgs A, con
   if (k >= A.kmax[c]) return;
   const long long ix = g.at(k, c);
   Pools p;
-  load_pools(A, P.autotrophs, ix, false, p);
+  load_pools(A, P.autotrophs, ix, p);
   const double KPARdz = kpar_dz(p.Chl, A.dz[ix]);
   A.scratch[(long long)S_KPARDZ * A.splane + ix] = KPARdz;
   A.scratch[(long long)S_ATT * A.splane + ix] = exp(-KPARdz);
@@ -152,15 +170,25 @@ __global__ __launch_bounds__(kBlockCol) void bgc_parscan_kernel(const BgcKernelA
 // accumulators stay live across iterations (the fully unrolled form needed 293 registers).
 struct Pool1 { double Chl, C, Fe, Si, Ca; };
 
-// clamped, zero-masked pools of one autotroph (BGC_mod.F90:764-785, 826-844)
-__device__ __forceinline__ Pool1 load_pool(const BgcKernelArgs& A, const obgc_autotroph& t, long long ix) {
+// raw pools of one autotroph; every load is unconditional (missing Si / CaCO3 slots re-read the C plane)
+__device__ __forceinline__ Pool1 load_pool_raw(const BgcKernelArgs& A, const obgc_autotroph& t, long long ix) {
   const long long pl = A.g.plane;
   Pool1 p;
-  p.Chl = dmax(0.0, A.tracers[(long long)(t.Chl_ind - 1) * pl + ix]);
-  p.C = dmax(0.0, A.tracers[(long long)(t.C_ind - 1) * pl + ix]);
-  p.Fe = dmax(0.0, A.tracers[(long long)(t.Fe_ind - 1) * pl + ix]);
-  p.Si = (t.Si_ind > 0) ? dmax(0.0, A.tracers[(long long)(t.Si_ind - 1) * pl + ix]) : 0.0;
-  p.Ca = (t.CaCO3_ind > 0) ? dmax(0.0, A.tracers[(long long)(t.CaCO3_ind - 1) * pl + ix]) : 0.0;
+  p.Chl = A.tracers[(long long)(t.Chl_ind - 1) * pl + ix];
+  p.C = A.tracers[(long long)(t.C_ind - 1) * pl + ix];
+  p.Fe = A.tracers[(long long)(t.Fe_ind - 1) * pl + ix];
+  p.Si = A.tracers[(long long)((t.Si_ind > 0 ? t.Si_ind : t.C_ind) - 1) * pl + ix];
+  p.Ca = A.tracers[(long long)((t.CaCO3_ind > 0 ? t.CaCO3_ind : t.C_ind) - 1) * pl + ix];
+  return p;
+}
+
+// clamps and zero-mask (BGC_mod.F90:764-785, 826-844)
+__device__ __forceinline__ Pool1 mask_pool(const obgc_autotroph& t, Pool1 p) {
+  p.Chl = dmax(0.0, p.Chl);
+  p.C = dmax(0.0, p.C);
+  p.Fe = dmax(0.0, p.Fe);
+  p.Si = (t.Si_ind > 0) ? dmax(0.0, p.Si) : 0.0;
+  p.Ca = (t.CaCO3_ind > 0) ? dmax(0.0, p.Ca) : 0.0;
   bool empty = p.Chl == 0.0 || p.C == 0.0 || p.Fe == 0.0;
   if (t.Si_ind > 0) empty = empty || p.Si == 0.0;
   if (empty) { p.Chl = 0.0; p.C = 0.0; p.Fe = 0.0; p.Si = 0.0; p.Ca = 0.0; }
@@ -173,7 +201,7 @@ __device__ __forceinline__ double sel4(const double (&v)[4], int a) {
 }
 
 template <bool DIAG>
-__global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+__device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc_params& P) {
   const GridView& g = A.g;
   const long long ncell = (long long)g.nlev * g.ncol;
   const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
@@ -184,14 +212,32 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
   const long long ix = g.at(k, c), pl = g.plane;
   const obgc_bgc_diag& D = A.diag;
   const obgc_autotroph* at = P.autotrophs;
-  int kmax = A.kmax[c];
-  if (kmax > g.nlev) kmax = g.nlev;
-
-#define TRC(slot) dmax(0.0, A.tracers[(long long)((slot)-1) * pl + ix])
+#define RAW(slot) A.tracers[(long long)((slot)-1) * pl + ix]
 #define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
 #define SCR(s) A.scratch[(long long)(s) * A.splane + ix]
 #define ST_KC(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
 #define ST_KCA(name, a, v) do { if (DIAG && D.name) D.name[(long long)(a) * pl + ix] = (v); } while (0)
+
+  // Every global load of the kernel is issued here, back to back, before anything waits: ~45 independent
+  // requests per lane and a single memory round trip per wavefront.  Cells below the sea floor load too (valid
+  // addresses, values discarded) so that the kmax test does not cost a round trip of its own.
+  int kmax = A.kmax[c];
+  const double lat = A.lat[c];
+  const double T = A.temp[ix], dz = A.dz[ix], zc = A.zmid[ix];
+  const double r_PO4 = RAW(P.ind[0]), r_NO3 = RAW(P.ind[1]), r_SiO3 = RAW(P.ind[2]), r_NH4 = RAW(P.ind[3]), r_Fe = RAW(P.ind[4]),
+               r_O2 = RAW(P.ind[5]), r_DOC = RAW(P.ind[9]), r_DON = RAW(P.ind[10]), r_DOFe = RAW(P.ind[11]), r_DOP = RAW(P.ind[12]),
+               r_DOPr = RAW(P.ind[13]), r_DONr = RAW(P.ind[14]), r_zooC = RAW(P.ind[15]);
+  const double PAR_in = SCR(S_PARIN), KPARdz = SCR(S_KPARDZ), att = SCR(S_ATT);
+  double r_salt = 0.0, ztop = 0.0;
+  if (DIAG) {
+    r_salt = A.salt[ix];
+    ztop = A.zbot[g.at(k > 0 ? k - 1 : 0, c)];
+    if (k == 0) ztop = 0.0;
+  }
+  Pool1 raw[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) raw[a] = load_pool_raw(A, at[a], ix);
+  if (kmax > g.nlev) kmax = g.nlev;
 
   if (k >= kmax) {
     // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727)
@@ -218,20 +264,59 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
   }
 
   const double T0K = P.T0_Kelvin_BGC;
-  const double lat = A.lat[c];
   const bool north = lat >= 0.0, south_or_eq = lat <= 0.0;
-  const double T = A.temp[ix], dz = A.dz[ix], zc = A.zmid[ix], zb = A.zbot[ix];
   // clamped local copies (747-762)
-  const double PO4 = TRC(P.ind[0]), NO3 = TRC(P.ind[1]), SiO3 = TRC(P.ind[2]), NH4 = TRC(P.ind[3]), Fe = TRC(P.ind[4]),
-               O2 = TRC(P.ind[5]), DOC = TRC(P.ind[9]), DON = TRC(P.ind[10]), DOFe = TRC(P.ind[11]), DOP = TRC(P.ind[12]),
-               DOPr = TRC(P.ind[13]), DONr = TRC(P.ind[14]), zooC = TRC(P.ind[15]);
+  const double PO4 = dmax(0.0, r_PO4), NO3 = dmax(0.0, r_NO3), SiO3 = dmax(0.0, r_SiO3), NH4 = dmax(0.0, r_NH4), Fe = dmax(0.0, r_Fe),
+               DOP = dmax(0.0, r_DOP), zooC = dmax(0.0, r_zooC);
 
   // light (907-924): attenuation and PAR entering the level come from the att / scan kernels
-  const double PAR_in = SCR(S_PARIN);
-  const double KPARdz = SCR(S_KPARDZ);
-  const double att = SCR(S_ATT);
   const double PAR_out = PAR_in * att;
   const double PAR_avg = PAR_in * (1.0 - att) / KPARdz;
+
+  // Everything below the autotroph loop that needs a global LOAD is evaluated now and parked in LDS: loads and
+  // stores retire through one in-order counter, so a load issued after the loop's ~100 diagnostic stores would
+  // wait for every one of them to be acknowledged.  From here on the kernel only stores.
+  //   DOM remineralisation (1436-1461), nitrification (1554-1561), the O2 weights of denitrification and
+  //   O2 consumption (1569-1577, 1784-1790), AOU, the 100 m weight of the Chl integral
+  __shared__ double s_tail[9][kBlockCell];
+  const int tid = threadIdx.x;
+  double aou = 0.0;
+  {
+    const double O2 = dmax(0.0, r_O2), DOC = dmax(0.0, r_DOC), DON = dmax(0.0, r_DON), DOFe = dmax(0.0, r_DOFe),
+                 DOPr = dmax(0.0, r_DOPr), DONr = dmax(0.0, r_DONr);
+    double DOC_remin = DOC * DOC_REMINR, DON_remin = DON * DON_REMINR, DOFe_remin = DOFe * DOFE_REMINR,
+           DOP_remin = DOP * DOP_REMINR, DONr_remin, DOPr_remin;
+    if (PAR_avg > 1.0) {
+      DONr_remin = DONr * DONR_REMINR;
+      DOPr_remin = DOPr * DOPR_REMINR;
+    } else {   // below the euphotic zone (1451-1461)
+      DONr_remin = DONr * (1.0 / (365.0 * 670.0)) * DPS;
+      DOPr_remin = DOPr * (1.0 / (365.0 * 460.0)) * DPS;
+      DOC_remin = DOC_remin * 0.0685;
+      DON_remin = DON_remin * 0.1;
+      DOFe_remin = DOFe_remin * 0.05;
+      DOP_remin = DOP_remin * 0.05;
+    }
+    double NITRIF;
+    if (PAR_out < P.parm_nitrif_par_lim) {
+      NITRIF = P.parm_kappa_nitrif * NH4;
+      if (PAR_in > P.parm_nitrif_par_lim) NITRIF = NITRIF * log(PAR_out / P.parm_nitrif_par_lim) / (-KPARdz);
+    } else NITRIF = 0.0;
+    double wd = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
+    wd = dmin(dmax(wd, 0.0), 1.0);
+    if (NO3 == 0.0) wd = 0.0;
+    double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
+    wo = dmin(dmax(wo, 0.0), 1.0);
+    s_tail[0][tid] = DOC_remin; s_tail[1][tid] = DON_remin; s_tail[2][tid] = DOFe_remin; s_tail[3][tid] = DOP_remin;
+    s_tail[4][tid] = DONr_remin; s_tail[5][tid] = DOPr_remin; s_tail[6][tid] = NITRIF; s_tail[7][tid] = wd * (DOC_remin / DENITRIF_C_N);
+    s_tail[8][tid] = wo;
+    if (DIAG && D.AOU) aou = o2sat(T, r_salt, T0K) - O2;
+  }
+  double pt100 = 0.0;   // thickness of this level above 100 m (1940-1945)
+  if (DIAG) {
+    const double w = dmin(100.0e2 - ztop, dz);
+    pt100 = (w > 0.0) ? w : 0.0;
+  }
 
   // temperature response and loss thresholds (1041-1055)
   const double Tfunc = pow(Q_10, ((T + T0K) - (TREF + T0K)) / 10.0);
@@ -240,15 +325,19 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
   else f_loss_thres = 1.0;
 
   // ---- pre-pass: Pprime (1072-1094), grazing (1297-1324), zooplankton losses (1395-1415) ----
+  // The masked pools are read from HBM once and parked in LDS for the rolled loop below (each lane only
+  // ever touches its own column of the array, so no barrier is needed).
+  __shared__ double s_pool[20][kBlockCell];
   double Pprime[4], graze[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const Pool1 p = load_pool(A, at[a], ix);
+    const Pool1 p = mask_pool(at[a], raw[a]);
+    s_pool[a][tid] = p.Chl; s_pool[4 + a][tid] = p.C; s_pool[8 + a][tid] = p.Fe; s_pool[12 + a][tid] = p.Si; s_pool[16 + a][tid] = p.Ca;
     double C_loss_thres = f_loss_thres * at[a].loss_thres;
     if (at[a].temp_function == TFNC_Q10) {
       if (T < at[a].temp_thres) C_loss_thres = f_loss_thres * at[a].loss_thres2;
     } else if (at[a].temp_function == TFNC_QUASI_MMRT) {
-      const double tmpTmax = north ? at[a].temp_thresN : at[a].temp_thresS;
+      const double tmpTmax = north ? uniform(at[a].temp_thresN) : uniform(at[a].temp_thresS);
       if (T > tmpTmax) C_loss_thres = f_loss_thres * at[a].loss_thres2;
     }
     Pprime[a] = dmax(p.C - C_loss_thres, 0.0);
@@ -272,6 +361,7 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
     w2 = w2 + (graze[a] + EPSC * EPSTINV);
   }
   const double f_zoo_detr = w1 / w2;
+  if (DIAG) { ST_KC(AOU, aou); ST_KC(PAR_avg, PAR_avg); }   // first stores: every load has been issued by now
   const double Zprime = dmax(zooC - f_loss_thres * LOSS_THRES_ZOO, 0.0);
   const double zoo_loss = (P.parm_z_mort2_0 * pow(Zprime, 1.5) + P.parm_z_mort_0 * Zprime) * Tfunc;
   const double zoo_loss_doc = (1.0 - P.parm_labile_ratio) * (1.0 - f_zoo_detr) * zoo_loss;
@@ -289,7 +379,7 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
 #pragma unroll 1
   for (int a = 0; a < 4; ++a) {
     const obgc_autotroph& t = at[a];
-    const Pool1 p = load_pool(A, t, ix);
+    const Pool1 p{s_pool[a][tid], s_pool[4 + a][tid], s_pool[8 + a][tid], s_pool[12 + a][tid], s_pool[16 + a][tid]};
     const double Pp = sel4(Pprime, a), gz = sel4(graze, a);
     // quotas for growth (850-898)
     const double Cden = p.C + EPSC;
@@ -336,8 +426,8 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
     double PCmax = t.PCref * f_nut * Tfunc;
     if (T < t.temp_thres) PCmax = 0.0;
     if (t.temp_function == TFNC_QUASI_MMRT) {
-      const double tmpTopt = north ? t.temp_optN : t.temp_optS;
-      const double tmpTmax = north ? t.temp_thresN : t.temp_thresS;
+      const double tmpTopt = north ? uniform(t.temp_optN) : uniform(t.temp_optS);
+      const double tmpTmax = north ? uniform(t.temp_thresN) : uniform(t.temp_thresS);
       PCmax = PCmax * dmin(1.0, ((tmpTmax - T) / (tmpTmax - tmpTopt)));
       if (T > tmpTmax) PCmax = 0.0;
     }
@@ -460,58 +550,21 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
   ST_KC(photoC_NO3_TOT, d_pCNO3);
   ST_KC(auto_graze_TOT, sum4(graze));
 
-  // ---- DOM (1421-1461) ----
+  // ---- DOM (1421-1461): remineralisation terms come from the prologue ----
   const double DOC_prod = zoo_loss_doc + s_ls_doc + s_gr_doc;
   const double DON_prod = QN * DOC_prod;
-  double DOC_remin = DOC * DOC_REMINR, DON_remin = DON * DON_REMINR, DOFe_remin = DOFe * DOFE_REMINR,
-         DOP_remin = DOP * DOP_REMINR, DONr_remin, DOPr_remin;
-  if (PAR_avg > 1.0) {
-    DONr_remin = DONr * DONR_REMINR;
-    DOPr_remin = DOPr * DOPR_REMINR;
-  } else {   // below the euphotic zone (1451-1461)
-    DONr_remin = DONr * (1.0 / (365.0 * 670.0)) * DPS;
-    DOPr_remin = DOPr * (1.0 / (365.0 * 460.0)) * DPS;
-    DOC_remin = DOC_remin * 0.0685;
-    DON_remin = DON_remin * 0.1;
-    DOFe_remin = DOFe_remin * 0.05;
-    DOP_remin = DOP_remin * 0.05;
-  }
+  const double DOC_remin = s_tail[0][tid], DON_remin = s_tail[1][tid], DOFe_remin = s_tail[2][tid], DOP_remin = s_tail[3][tid],
+               DONr_remin = s_tail[4][tid], DOPr_remin = s_tail[5][tid], NITRIF = s_tail[6][tid], D0 = s_tail[7][tid],
+               wo = s_tail[8][tid];
   const double prodPOC = f_zoo_detr * zoo_loss + s_gr_poc + s_agg + s_ls_poc;        // 1467-1468
 
-  // ---- decay factors of the sinking classes across this level (2273-2339) ----
-  double scalelength;
-  {
-    const double* sz = P.parm_scalelen_z;
-    const double* sv = P.parm_scalelen_vals;
-    if (zb < sz[0]) scalelength = sv[0];
-    else if (zb >= sz[3]) scalelength = sv[3];
-    else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
-    else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
-    else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
-  }
-  const double TfuncS = pow(1.5, ((T + T0K) - (TREF + T0K)) / 10.0);
-  double poc_diss = P.parm_POC_diss;
-  if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
-  else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
-  poc_diss = scalelength * poc_diss;
-  double sio2_diss = scalelength * P.parm_SiO2_diss;
-  const double caco3_diss = scalelength * P.parm_CaCO3_diss;
-  const double dust_diss = scalelength * DUST_DISS;
-  sio2_diss = sio2_diss / TfuncS;
   SCR(S_PRODPOC) = prodPOC; SCR(S_PRODCA) = prodCa; SCR(S_PRODSI) = prodSi; SCR(S_PFELOC) = PfeLoc;
-  SCR(S_DEC_POC) = exp(-dz / poc_diss); SCR(S_DEC_SIO2) = exp(-dz / sio2_diss);
-  SCR(S_DEC_CACO3) = exp(-dz / caco3_diss); SCR(S_DEC_DUST) = exp(-dz / dust_diss);
-  SCR(S_DEC_HARD) = exp(-dz / 4.0e6); SCR(S_DEC_HARDDUST) = exp(-dz / 1.2e7);
-  SCR(S_POC_DISS) = poc_diss; SCR(S_SIO2_DISS) = sio2_diss; SCR(S_CACO3_DISS) = caco3_diss;
 
-  // ---- nitrification (1554-1561) ----
-  double NITRIF;
-  if (PAR_out < P.parm_nitrif_par_lim) {
-    NITRIF = P.parm_kappa_nitrif * NH4;
-    if (PAR_in > P.parm_nitrif_par_lim) NITRIF = NITRIF * log(PAR_out / P.parm_nitrif_par_lim) / (-KPARdz);
-  } else NITRIF = 0.0;
-  SCR(S_DOC_REMIN) = DOC_remin; SCR(S_NITRIF) = NITRIF; SCR(S_ZLD) = zoo_loss_dic; SCR(S_LSDIC) = s_ls_dic;
-  SCR(S_GRDIC) = s_gr_dic; SCR(S_NEXC) = nexc; SCR(S_CAX) = ca_x; SCR(S_CAPROD) = ca_prod;
+  // ---- local parts of denitrification (1569-1577) and O2 consumption (1784-1790): the terms that do not
+  //      involve the particle remineralisation, weighted in the prologue; the sweep adds  w * (remin terms)  ----
+  const double S3 = zoo_loss_dic + s_ls_dic + s_gr_dic;
+  const double CAD = ca_x - ca_prod;
+  const double OC0 = wo * ((DOC_remin + S3) / REMIN_D_C_O2 + (2.0 * NITRIF));
 
   // ---- tendencies that do not see the particles (1703-1723) ----
   const double t_zooC = s_gr_zoo - zoo_loss;
@@ -523,39 +576,57 @@ __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernel
   TEND(P.ind[10]) = t_don;
   TEND(P.ind[11]) = DOFe_prod - DOFe_remin;
   TEND(P.ind[12]) = t_dop;
-  // ---- particle-dependent tendencies: the local part waits in the caller's tendency plane ----
-  TEND(P.ind[1]) = sNO3V;                                                             // 1583
-  TEND(P.ind[3]) = -sNH4V - NITRIF + DON_remin + DONr_remin;                          // 1585
-  TEND(P.ind[4]) = ((QFE_ZOO * zoo_loss_dic) + DOFe_remin - sPhotoFe) + L_fe_a;       // 1598-1605
-  TEND(P.ind[2]) = L_sio3_a;                                                          // 1620-1628
-  TEND(P.ind[0]) = (DOP_remin + DOPr_remin - sPO4V) + L_po4_a;                        // 1643-1661
-  TEND(P.ind[14]) = (DON_prod * DONREFRACT) - DONr_remin;                             // 1714
-  TEND(P.ind[13]) = (DOP_prod * DOPREFRACT) - DOPr_remin;                             // 1720
-  TEND(P.ind[6]) = s_ls_dic + s_gr_dic - sPhotoC + DOC_remin;                         // 1729-1731
-  TEND(P.ind[5]) = O2_PRODUCTION;                                                     // 1790
+  // ---- particle-dependent tendencies: everything local is folded here and waits in the caller's
+  //      tendency plane; the sweep adds the remineralisation terms (listed with each line) ----
+  TEND(P.ind[1]) = (NITRIF - sNO3V) - D0;                                             // 1583: - wd*((reminPOC-OTHER)/C - SED) - SED
+  TEND(P.ind[3]) = ((-sNH4V - NITRIF + DON_remin + DONr_remin) + QN * S3) + nexc;     // 1585-1592: + QN*(1-DONrefract)*reminPOC
+  TEND(P.ind[4]) = ((QFE_ZOO * zoo_loss_dic) + DOFe_remin - sPhotoFe) + L_fe_a;       // 1598-1605: + reminFe - Fe_scavenge
+  TEND(P.ind[2]) = L_sio3_a;                                                          // 1620-1628: + reminSi
+  TEND(P.ind[0]) = ((DOP_remin + DOPr_remin - sPO4V) + L_po4_a) + QP_ZOO_POM * zoo_loss_dic;   // 1643-1661: + Qp*(1-DOPrefract)*reminPOC
+  TEND(P.ind[14]) = (DON_prod * DONREFRACT) - DONr_remin;                             // 1714: + reminPOC*DONrefract*Q
+  TEND(P.ind[13]) = (DOP_prod * DOPREFRACT) - DOPr_remin;                             // 1720: + reminPOC*DOPrefract*Qp
+  TEND(P.ind[6]) = ((s_ls_dic + s_gr_dic - sPhotoC + DOC_remin) + zoo_loss_dic) + CAD;   // 1729-1739: + reminPOC + reminCaCO3
+  TEND(P.ind[8]) = 2.0 * CAD;                                                         // 1749-1759: - t_no3 + t_nh4 + 2 reminCaCO3
+  TEND(P.ind[5]) = O2_PRODUCTION - OC0;                                               // 1790: - wo*(reminPOC - SED*C - OTHER)/R
 
   if (DIAG) {
     ST_KC(NO3_RESTORE, 0.0); ST_KC(SiO3_RESTORE, 0.0); ST_KC(PO4_RESTORE, 0.0);       // lrest_* never set (131-134)
     ST_KC(NITRIF, NITRIF); ST_KC(O2_PRODUCTION, O2_PRODUCTION);
-    if (D.AOU) D.AOU[ix] = o2sat(T, A.salt[ix], T0K) - O2;
-    ST_KC(PAR_avg, PAR_avg); ST_KC(zoo_loss, zoo_loss);
+    ST_KC(zoo_loss, zoo_loss);
     ST_KC(DOC_prod, DOC_prod); ST_KC(DOC_remin, DOC_remin); ST_KC(DON_prod, DON_prod); ST_KC(DON_remin, DON_remin);
     ST_KC(DOP_prod, DOP_prod); ST_KC(DOP_remin, DOP_remin); ST_KC(DOFe_prod, DOFe_prod); ST_KC(DOFe_remin, DOFe_remin);
     // local parts of the conservation integrals (1875-1938); the sweep adds the particle-dependent tendencies
-    const double ztop = (k > 0) ? A.zbot[g.at(k - 1, c)] : 0.0;
-    w2 = dmin(100.0e2 - ztop, dz);
-    const double pt100 = (w2 > 0.0) ? w2 : 0.0;
+    SCR(S_OC0) = OC0; SCR(S_D0) = D0;
     SCR(S_JC) = t_doc + t_zooC + sC + sCa;
     SCR(S_JN) = t_don + QN * t_zooC + QN * sC - sNfix;
     SCR(S_JP) = t_dop + QP_ZOO_POM * t_zooC + sQpC;
     SCR(S_JSI) = sSi;
     SCR(S_CHL100) = chl * pt100;
   }
-#undef TRC
+#undef RAW
 #undef TEND
 #undef SCR
 #undef ST_KC
 #undef ST_KCA
+}
+
+// FUSE = 1: the wavefront goes on to solve the carbonate system of its own cells (obgc_co2.h) after the
+// ecosystem terms.  The two halves want different things from the SIMD -- ~150 stores per lane drained by the
+// memory pipeline against ~6 600 fp64 VALU instructions -- and as separate kernels their waves compete for
+// the register file instead of overlapping (the cell kernel fills a SIMD with two waves).  In one wave the
+// stores drain under the Newton iterations and the co-resident wave's loads hide under them.
+template <bool DIAG, int FUSE>
+__global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  cell_body<DIAG>(A, P);
+  if (FUSE) {
+    const GridView& g = A.g;
+    const long long ncell = (long long)g.nlev * g.ncol;
+    const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
+    int k, c;
+    if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+    else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+    carbonate_cell(A, P.ind[6], P.ind[8], P.ind[0], P.ind[2], idx < ncell, k, c);
+  }
 }
 
 // ------------------------------------------------------------------------------ particle sweep
@@ -566,11 +637,10 @@ struct Flux { double s, h; };   // soft / hard sub-class flux leaving a level
 // other way: 100k columns are only 1 563 wavefronts).
 template <bool DIAG>
 struct LevelIn {
-  double dz, zb, fesed, NO3, Fe, O2;
-  double prodPOC, prodCa, prodSi, PfeLoc, dPOC, dSi, dCa, dDust, dHard, dHardDust, poc_diss, sio2_diss, caco3_diss;
-  double DOC_remin, NITRIF, zld, lsdic, grdic, nexc, ca_x, ca_prod;
-  double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_o2;
-  double jc, jn, jp, jsi;   // DIAG only
+  double dz, zb, fesed, T, NO3, Fe, O2;
+  double prodPOC, prodCa, prodSi, PfeLoc;
+  double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_alk, L_o2;
+  double oc0, d0, jc, jn, jp, jsi;   // DIAG only
 };
 
 template <bool DIAG>
@@ -579,17 +649,12 @@ __device__ __forceinline__ void load_level(const BgcKernelArgs& A, const obgc_bg
 #define TRC(slot) dmax(0.0, A.tracers[(long long)((slot)-1) * pl + ix])
 #define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
 #define SCR(s) A.scratch[(long long)(s) * sp + ix]
-  L.dz = A.dz[ix]; L.zb = A.zbot[ix]; L.fesed = A.fesed[ix];
+  L.dz = A.dz[ix]; L.zb = A.zbot[ix]; L.fesed = A.fesed[ix]; L.T = A.temp[ix];
   L.NO3 = TRC(P.ind[1]); L.Fe = TRC(P.ind[4]); L.O2 = TRC(P.ind[5]);
   L.prodPOC = SCR(S_PRODPOC); L.prodCa = SCR(S_PRODCA); L.prodSi = SCR(S_PRODSI); L.PfeLoc = SCR(S_PFELOC);
-  L.dPOC = SCR(S_DEC_POC); L.dSi = SCR(S_DEC_SIO2); L.dCa = SCR(S_DEC_CACO3); L.dDust = SCR(S_DEC_DUST);
-  L.dHard = SCR(S_DEC_HARD); L.dHardDust = SCR(S_DEC_HARDDUST);
-  L.poc_diss = SCR(S_POC_DISS); L.sio2_diss = SCR(S_SIO2_DISS); L.caco3_diss = SCR(S_CACO3_DISS);
-  L.DOC_remin = SCR(S_DOC_REMIN); L.NITRIF = SCR(S_NITRIF); L.zld = SCR(S_ZLD); L.lsdic = SCR(S_LSDIC); L.grdic = SCR(S_GRDIC);
-  L.nexc = SCR(S_NEXC); L.ca_x = SCR(S_CAX); L.ca_prod = SCR(S_CAPROD);
   L.L_no3 = TEND(P.ind[1]); L.L_nh4 = TEND(P.ind[3]); L.L_fe = TEND(P.ind[4]); L.L_sio3 = TEND(P.ind[2]); L.L_po4 = TEND(P.ind[0]);
-  L.L_donr = TEND(P.ind[14]); L.L_dopr = TEND(P.ind[13]); L.L_dic = TEND(P.ind[6]); L.L_o2 = TEND(P.ind[5]);
-  if (DIAG) { L.jc = SCR(S_JC); L.jn = SCR(S_JN); L.jp = SCR(S_JP); L.jsi = SCR(S_JSI); }
+  L.L_donr = TEND(P.ind[14]); L.L_dopr = TEND(P.ind[13]); L.L_dic = TEND(P.ind[6]); L.L_alk = TEND(P.ind[8]); L.L_o2 = TEND(P.ind[5]);
+  if (DIAG) { L.oc0 = SCR(S_OC0); L.d0 = SCR(S_D0); L.jc = SCR(S_JC); L.jn = SCR(S_JN); L.jp = SCR(S_JP); L.jsi = SCR(S_JSI); }
 #undef TRC
 #undef TEND
 #undef SCR
@@ -626,10 +691,30 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
     if (k + 1 < kmax) load_level<DIAG>(A, P, g.at(k + 1, c), nxt);   // in flight while this level is evaluated
     const double dz = cur.dz, zb = cur.zb, NO3 = cur.NO3, Fe = cur.Fe, O2 = cur.O2;
     const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
-    const double decay_POC_E = cur.dPOC, decay_SiO2 = cur.dSi, decay_CaCO3 = cur.dCa, decay_dust = cur.dDust,
-                 DECAY_Hard = cur.dHard, DECAY_HardDust = cur.dHardDust, poc_diss = cur.poc_diss, sio2_diss = cur.sio2_diss,
-                 caco3_diss = cur.caco3_diss;
-    const double DOC_remin = cur.DOC_remin, NITRIF = cur.NITRIF, zoo_loss_dic = cur.zld, s_ls_dic = cur.lsdic, s_gr_dic = cur.grdic;
+
+    // dissolution length scales and decay factors across this level (2273-2339): functions of the inputs
+    // this kernel reads anyway, so they are evaluated here instead of travelling through HBM
+    double scalelength;
+    {
+      const double* sz = P.parm_scalelen_z;
+      const double* sv = P.parm_scalelen_vals;
+      if (zb < sz[0]) scalelength = sv[0];
+      else if (zb >= sz[3]) scalelength = sv[3];
+      else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
+      else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
+      else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
+    }
+    const double TfuncS = pow(1.5, ((cur.T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC)) / 10.0);
+    double poc_diss = P.parm_POC_diss;
+    if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
+    else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
+    poc_diss = scalelength * poc_diss;
+    double sio2_diss = scalelength * P.parm_SiO2_diss;
+    const double caco3_diss = scalelength * P.parm_CaCO3_diss;
+    const double dust_diss = scalelength * DUST_DISS;
+    sio2_diss = sio2_diss / TfuncS;
+    const double decay_POC_E = exp(-dz / poc_diss), decay_SiO2 = exp(-dz / sio2_diss), decay_CaCO3 = exp(-dz / caco3_diss),
+                 decay_dust = exp(-dz / dust_diss), DECAY_Hard = exp(-dz / 4.0e6), DECAY_HardDust = exp(-dz / 1.2e7);
 
     // iron scavenging onto the particles LEAVING the level above (1510-1529)
     double Fe_scav_rate = P.parm_fe_scavenge_rate0;
@@ -708,25 +793,25 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
       fCa = Flux{0.0, 0.0}; fSi = Flux{0.0, 0.0}; fDust = Flux{0.0, 0.0}; fPOC = Flux{0.0, 0.0}; fFe = Flux{0.0, 0.0};
     }
 
-    // ---- denitrification (1569-1577) and the particle-dependent tendencies (1583-1790) ----
-    double w1 = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
-    w1 = dmin(dmax(w1, 0.0), 1.0);
-    if (NO3 == 0.0) w1 = 0.0;
-    const double DENITRIF = w1 * ((DOC_remin + reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
-    const double t_no3 = 0.0 + NITRIF - DENITRIF - SED_DENITRIF - cur.L_no3;
-    const double t_nh4 = cur.L_nh4 + QN * (zoo_loss_dic + s_ls_dic + s_gr_dic + reminPOC * (1.0 - DONREFRACT)) + cur.nexc;
+    // ---- denitrification (1569-1577) and the particle-dependent tendencies (1583-1790): the cell kernel
+    //      left every local term in the tendency planes; only the remineralisation terms are added here ----
+    double wd = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
+    wd = dmin(dmax(wd, 0.0), 1.0);
+    if (NO3 == 0.0) wd = 0.0;
+    const double den_p = wd * ((reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
+    const double t_no3 = (cur.L_no3 - den_p) - SED_DENITRIF;
+    const double t_nh4 = cur.L_nh4 + QN * (reminPOC * (1.0 - DONREFRACT));
     const double t_fe = (reminFe + cur.L_fe) - Fe_scavenge;
     const double t_sio3 = reminSi + cur.L_sio3;
-    const double t_po4 = cur.L_po4 + QP_ZOO_POM * ((1.0 - DOPREFRACT) * reminPOC + zoo_loss_dic);
+    const double t_po4 = cur.L_po4 + QP_ZOO_POM * ((1.0 - DOPREFRACT) * reminPOC);
     const double t_donr = cur.L_donr + (reminPOC * DONREFRACT * QN);
     const double t_dopr = cur.L_dopr + (reminPOC * DOPREFRACT * QP_ZOO_POM);
-    const double t_dic = (cur.L_dic + reminPOC + zoo_loss_dic + reminCa) + cur.ca_x - cur.ca_prod;
-    const double t_alk = (-t_no3 + t_nh4 + 2.0 * reminCa) + 2.0 * (cur.ca_x - cur.ca_prod);
-    w1 = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
-    w1 = dmin(dmax(w1, 0.0), 1.0);
-    const double O2_CONSUMPTION =
-        w1 * ((reminPOC + DOC_remin - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN + zoo_loss_dic + s_ls_dic + s_gr_dic) / REMIN_D_C_O2 +
-              (2.0 * NITRIF));
+    const double t_dic = (cur.L_dic + reminPOC) + reminCa;
+    const double t_alk = (-t_no3 + t_nh4 + 2.0 * reminCa) + cur.L_alk;
+    double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
+    wo = dmin(dmax(wo, 0.0), 1.0);
+    const double oc_p = wo * ((reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN) / REMIN_D_C_O2);
+    double w1;
     TEND(P.ind[1], ix) = t_no3;
     TEND(P.ind[3], ix) = t_nh4;
     TEND(P.ind[4], ix) = t_fe;
@@ -737,7 +822,7 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
     TEND(P.ind[6], ix) = t_dic;
     TEND(P.ind[7], ix) = A.alt_co2_use_eco ? t_dic : 0.0;
     TEND(P.ind[8], ix) = t_alk;
-    TEND(P.ind[5], ix) = cur.L_o2 - O2_CONSUMPTION;
+    TEND(P.ind[5], ix) = cur.L_o2 - oc_p;
 
     if (DIAG) {   // 2637-2694, 1563-1577, 1866-1868
       ST_KC(POC_FLUX_IN, inPOC.s + inPOC.h); ST_KC(POC_PROD, prodPOC); ST_KC(POC_REMIN, reminPOC);
@@ -749,7 +834,8 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
       ST_KC(SedDenitrif, SED_DENITRIF * dz); ST_KC(OtherRemin, OTHER_REMIN * dz);
       ST_KC(ponToSed, (sedPOC * QN)); ST_KC(popToSed, (sedPOC * QP_ZOO_POM));
       ST_KC(dustToSed, sedDust); ST_KC(pfeToSed, sedFe);
-      ST_KC(DENITRIF, DENITRIF); ST_KC(O2_CONSUMPTION, O2_CONSUMPTION);
+      const double DENITRIF = cur.d0 + den_p;
+      ST_KC(DENITRIF, DENITRIF); ST_KC(O2_CONSUMPTION, cur.oc0 + oc_p);
       ST_KC(Fe_scavenge, Fe_scavenge); ST_KC(Fe_scavenge_rate, Fe_scav_rate);
       // conservation integrals (1870-1938): local parts from the cell kernel + the tendencies finished here
       const double w2 = dmin(100.0e2 - zbot_above, dz);
@@ -843,7 +929,8 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
 
 }  // namespace
 
-void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1) {
+void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1,
+                             int fuse_carbonate) {
   if (a.g.ncol <= 0) return;
   const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
   const long long ncell = (long long)a.g.nlev * a.g.ncol;
@@ -851,8 +938,13 @@ void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, h
   hipLaunchKernelGGL(bgc_att_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, p);
   hipLaunchKernelGGL(bgc_parscan_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a);
   if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
-  if (a.have_diag) hipLaunchKernelGGL(bgc_cell_kernel<true>, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
-  else hipLaunchKernelGGL(bgc_cell_kernel<false>, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  if (fuse_carbonate) {
+    if (a.have_diag) hipLaunchKernelGGL((bgc_cell_kernel<true, 1>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+    else hipLaunchKernelGGL((bgc_cell_kernel<false, 1>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  } else {
+    if (a.have_diag) hipLaunchKernelGGL((bgc_cell_kernel<true, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+    else hipLaunchKernelGGL((bgc_cell_kernel<false, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  }
   if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
 }
 

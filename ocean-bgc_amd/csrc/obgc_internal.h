@@ -32,14 +32,15 @@ inline GridView make_view(const obgc_grid& g) {
 
 // Hand-off between the cell-parallel ecosystem kernel and the column sweep: one fp64 plane per
 // slot, laid out exactly like the caller's (k,column) arrays (same index, plane stride splane).
+// Everything else the sweep needs is either recomputed from the inputs it reads anyway (scale lengths,
+// decay factors) or parked by the cell kernel in the caller's own tendency planes (ten coupled
+// tendencies whose local part is final and whose particle part the sweep adds).
 enum ScratchSlot {
   S_PARIN, S_ATT, S_KPARDZ,                    // PAR entering the level, exp(-KPARdz), KPARdz (att / scan kernels -> cell kernel)
   S_PRODPOC, S_PRODCA, S_PRODSI, S_PFELOC,     // particle production terms (P_iron without scavenging)
-  S_DEC_POC, S_DEC_SIO2, S_DEC_CACO3, S_DEC_DUST, S_DEC_HARD, S_DEC_HARDDUST,   // decay factors across the level
-  S_POC_DISS, S_SIO2_DISS, S_CACO3_DISS,       // dissolution length scales
-  S_DOC_REMIN, S_NITRIF, S_ZLD, S_LSDIC, S_GRDIC, S_NEXC, S_CAX, S_CAPROD,       // pieces of the 11 coupled tendencies
   S_NBASE,
-  S_JC = S_NBASE, S_JN, S_JP, S_JSI, S_CHL100, // diagnostics only: local parts of the column integrals
+  S_OC0 = S_NBASE, S_D0,                       // diagnostics only: local parts of O2_CONSUMPTION and DENITRIF
+  S_JC, S_JN, S_JP, S_JSI, S_CHL100,           //                   local parts of the column integrals
   S_NDIAG
 };
 
@@ -105,7 +106,8 @@ struct MacrosKernelArgs {
 // ---------------------------------------------------------------- launchers (one per .hip file)
 void launch_bgc_carbonate(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_zsat(const BgcKernelArgs& a, hipStream_t s);
-void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1);
+void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1,
+                             int fuse_carbonate);
 void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int lanes);
 void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_surface(const SurfKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
