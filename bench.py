@@ -42,10 +42,10 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, FMA counted as 2
 # algorithmic bytes per ACTIVE cell (split per kernel in DESIGN.md)
 BYTES_CARBONATE = {"none": 88, "full": 168}
 BYTES_ECOSYS = {"none": 472, "full": 1432}     # PAR scan + cell kernel + particle sweep together
-# the cell kernel alone: reads 27 tracers + T, dz, zmid, zbot + PAR_in, writes 19 final tendencies (+ 9 staged
-# ones and 21 hand-off scratch values that are engine-internal, not algorithmic); with diagnostics it also
-# writes the 72 per-autotroph and 21 of the (k,column) diagnostics and reads S and zbot(k-1)
-BYTES_CELL = {"none": (27 + 4 + 19) * 8, "full": (27 + 6 + 19 + 72 + 21) * 8}
+# the cell kernel alone: reads 27 tracers + T, dz, zmid, writes 19 final tendencies (+ 10 staged ones, 4 hand-off
+# scratch values and the 3 light planes it reads back, all engine-internal, not algorithmic); with diagnostics
+# it also writes the 72 per-autotroph and 21 of the (k,column) diagnostics and reads S and zbot(k-1)
+BYTES_CELL = {"none": (27 + 3 + 19) * 8, "full": (27 + 5 + 19 + 72 + 21) * 8}
 BYTES_DMS = {"none": 136, "full": 352}
 BYTES_MACROS = {"none": 88, "full": 136}
 
@@ -322,8 +322,9 @@ def main():
                     "other_kernel_ms": {"bgc_carbonate_kernel": t_car, "bgc_cell_kernel": t_cell,
                                         "ecosystem_par+cell+sweep": t_eco, "call_device_ms": t_call},
                     "whole_call_GBps": active_cells * (BYTES_CARBONATE[dk] + BYTES_ECOSYS[dk]) / (t_call * 1e-3) / 1e9,
-                    "note": "pointwise fp64 kinetics: the binding resource is fp64 VALU + software transcendentals, "
-                            "not HBM (SURVEY.md 8d); see DESIGN.md"}
+                    "note": "the cell kernel moves `traffic` bytes (hand-off + zero fill on top of the algorithmic "
+                            "ones) at the HBM rate a write-heavy stream reaches; the carbonate kernel beside it is "
+                            "bound by fp64 VALU issue (96 %); see DESIGN.md section 4"}
         out = {"metric": "column-level tracer updates/sec", "value": value, "unit": "updates/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -3,6 +3,7 @@
 // HIP kernels or returns a negative status.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,8 +19,9 @@ struct obgc_handle {
   unsigned flags = 0;
   hipStream_t s_main = nullptr;   // column-sweep kernels, copies, transposes
   hipStream_t s_aux = nullptr;    // cell-parallel carbonate kernel runs beside the sweep
+  hipStream_t s_aux2 = nullptr;   // column integrals (diagnostics) run beside both
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
-             ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+             ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_aux2_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool timed_valid = false, tr_valid = false, cell_valid = false;
   int sweep_lanes = 0;    // experiment knob OBGC_SWEEP_LANES: 16 / 32 / 64 active lanes per wavefront in the sweep, 0 = auto
   int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
@@ -55,6 +57,7 @@ int arena_reserve(obgc_handle* h, size_t bytes) {
   if (bytes <= h->arena_bytes) return OBGC_OK;
   HIP_TRY(h, hipStreamSynchronize(h->s_main));
   HIP_TRY(h, hipStreamSynchronize(h->s_aux));
+  HIP_TRY(h, hipStreamSynchronize(h->s_aux2));
   if (h->arena) (void)hipFree(h->arena);
   h->arena = nullptr;
   h->arena_bytes = 0;
@@ -284,11 +287,12 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   h->device = device_id;
   h->flags = flags;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->s_aux2, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return OBGC_ERR_HIP;
   }
-  hipEvent_t* evs[] = {&h->ev_begin, &h->ev_end, &h->ev_c0, &h->ev_c1, &h->ev_e0, &h->ev_e1, &h->ev_t0, &h->ev_t1, &h->ev_aux_done, &h->ev_k0, &h->ev_k1};
+  hipEvent_t* evs[] = {&h->ev_begin, &h->ev_end, &h->ev_c0, &h->ev_c1, &h->ev_e0, &h->ev_e1, &h->ev_t0, &h->ev_t1, &h->ev_aux_done, &h->ev_aux2_done, &h->ev_k0, &h->ev_k1};
   for (auto e : evs)
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
@@ -307,12 +311,14 @@ extern "C" int obgc_destroy(obgc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->s_main);
   (void)hipStreamSynchronize(h->s_aux);
+  if (h->s_aux2) (void)hipStreamSynchronize(h->s_aux2);
   if (h->arena) (void)hipFree(h->arena);
-  hipEvent_t evs[] = {h->ev_begin, h->ev_end, h->ev_c0, h->ev_c1, h->ev_e0, h->ev_e1, h->ev_t0, h->ev_t1, h->ev_aux_done, h->ev_k0, h->ev_k1};
+  hipEvent_t evs[] = {h->ev_begin, h->ev_end, h->ev_c0, h->ev_c1, h->ev_e0, h->ev_e1, h->ev_t0, h->ev_t1, h->ev_aux_done, h->ev_aux2_done, h->ev_k0, h->ev_k1};
   for (auto e : evs)
     if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(h->s_main);
   (void)hipStreamDestroy(h->s_aux);
+  if (h->s_aux2) (void)hipStreamDestroy(h->s_aux2);
   delete h;
   return OBGC_OK;
 }
@@ -320,6 +326,7 @@ extern "C" int obgc_destroy(obgc_handle* h) {
 extern "C" int obgc_sync(obgc_handle* h) {
   if (!h) return OBGC_ERR_INVALID;
   HIP_TRY(h, hipStreamSynchronize(h->s_aux));
+  HIP_TRY(h, hipStreamSynchronize(h->s_aux2));
   HIP_TRY(h, hipStreamSynchronize(h->s_main));
   return OBGC_OK;
 }
@@ -420,40 +427,28 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
 }
 
 // s_main: attenuation -> PAR scan -> cell kernel -> particle sweep.
-// s_aux : carbonate cells -> saturation-horizon scan -> column integrals.
-// The device is saturated by the sum of these kernels: releasing the carbonate kernel at t = 0 or when the
-// cell kernel ends gives the same step time within 2 % (OBGC_SCHED=1 selects the latter for experiments).
+// s_aux : carbonate cells -> saturation-horizon scan.
+// s_aux2: column integrals of the cell kernel's production profiles (diagnostics only).
+// OBGC_SCHED picks when the carbonate kernel is released: 1 (default) when the cell kernel ends, so that its
+// fp64 work overlaps the memory-bound sweep and the cell kernel has the register file to itself; 0 at t = 0;
+// 2 = solved inside the cell kernel's wavefronts (measured slower: two waves per SIMD cannot feed the VALU).
 int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
   launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1, h->sched == 2);
   h->cell_valid = true;
-  if (h->sched == 2) {   // carbonate solved inside the cell kernel's wavefronts
-    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
-    HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
-    HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
-    if (want_zsat) launch_bgc_zsat(K, h->s_aux);
-    launch_bgc_zint(K, h->bgc, h->s_aux);
-    HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
-    launch_bgc_ecosys_sweep(K, h->bgc, h->s_main, h->sweep_lanes);
-    HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
-    return OBGC_OK;
-  }
-  if (h->sched == 1) {
-    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
-  } else {
-    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_e0, 0));
-  }
+  HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->sched == 0 ? h->ev_e0 : h->ev_k1, 0));
   HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
-  launch_bgc_carbonate(K, h->bgc, h->s_aux);
+  if (h->sched != 2) launch_bgc_carbonate(K, h->bgc, h->s_aux);
   HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
-  if (h->sched != 1) HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));   // zint reads the cell kernel's profiles
   if (want_zsat) launch_bgc_zsat(K, h->s_aux);
-  launch_bgc_zint(K, h->bgc, h->s_aux);
   HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_aux2, h->ev_k1, 0));   // zint reads the cell kernel's profiles
+  launch_bgc_zint(K, h->bgc, h->s_aux2);
+  HIP_TRY(h, hipEventRecord(h->ev_aux2_done, h->s_aux2));
   launch_bgc_ecosys_sweep(K, h->bgc, h->s_main, h->sweep_lanes);
   HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux2_done, 0));
   return OBGC_OK;
 }
 

@@ -19,7 +19,7 @@ namespace obgc {
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 64;
 
 __global__ __launch_bounds__(kBlock) void bgc_carbonate_kernel(BgcKernelArgs A, int i_dic, int i_alk, int i_po4,
                                                               int i_sio3) {

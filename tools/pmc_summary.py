@@ -28,7 +28,7 @@ def per_kernel(d):
 
 
 def short(name):
-    for key in ("bgc_ecosys_kernel<true>", "bgc_ecosys_kernel<false>", "bgc_carbonate_kernel", "bgc_zsat_kernel",
+    for key in ("bgc_carbonate_kernel", "bgc_zsat_kernel", "bgc_att_kernel", "bgc_zint_kernel", "bgc_parscan_kernel",
                 "bgc_surface_kernel", "dms_kernel", "macros_kernel", "transpose_kernel", "bgc_par_kernel",
                 "bgc_cell_kernel", "bgc_sweep_kernel"):
         if key in name:
