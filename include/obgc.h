@@ -284,6 +284,31 @@ typedef struct {
 
 int obgc_macros_source_sink(obgc_handle *h, const obgc_macros_source_sink_args *a);
 
+/* ------------------------------------------- resident tracers
+ * NO reference counterpart: the reference returns tendencies and the host model owns the time
+ * integration.  For a host that keeps its tracers on the GPU between steps this is the step right
+ * after the path -- an explicit update that avoids moving 60 arrays over PCIe every step:
+ *
+ *   x(k,c,n) <- x(k,c,n) + dt * ( tend(k,c,n) + [k == 1] * net_flux(c,n) / dz(1,c) )      k <= kmax(c)
+ *   x        <- max(x, 0)                                                  if clamp_nonneg
+ *
+ * Cells below kmax(c) are left untouched.  DEVICE pointers only (grid.memspace = OBGC_MEM_DEVICE);
+ * both layouts.  net_flux is the (column, n) array *_SurfaceFluxes leaves in netFlux (NULL = none),
+ * dz the cell thickness in the same length unit as the flux (cm for this package). */
+typedef struct {
+  obgc_grid grid;
+  int ntracer;
+  double *tracers;            /* (k,column,ntracer), updated in place */
+  const double *tend;         /* (k,column,ntracer) */
+  const double *net_flux;     /* (column,ntracer) with leading dimension grid.ldc, or NULL */
+  const double *dz;           /* (k,column) */
+  const int *kmax;
+  double dt;
+  int clamp_nonneg;
+} obgc_apply_tendencies_args;
+
+int obgc_apply_tendencies(obgc_handle *h, const obgc_apply_tendencies_args *a);
+
 /* ----------------------------------------------- workload utilities (bench/tests)
  * Deterministic synthetic columns, generated on the device in the
  * engine's native COLFAST layout for global columns [col0, col0+ncol).  Bit-identical

@@ -120,6 +120,11 @@ class MacrosSourceSinkArgs(C.Structure):
     _fields_ = [("grid", Grid), ("tracers", _dptr), ("kmax", _dptr), ("tend", _dptr), ("diag", C.POINTER(MacrosDiag))]
 
 
+class ApplyTendenciesArgs(C.Structure):
+    _fields_ = [("grid", Grid), ("ntracer", C.c_int), ("tracers", _dptr), ("tend", _dptr), ("net_flux", _dptr), ("dz", _dptr),
+                ("kmax", _dptr), ("dt", C.c_double), ("clamp_nonneg", C.c_int)]
+
+
 class SynthArgs(C.Structure):
     _fields_ = [("nlev", C.c_int), ("ncol", C.c_int), ("col0", C.c_longlong), ("ld", C.c_longlong),
                 ("plane", C.c_longlong), ("ldc", C.c_longlong), ("ind", C.POINTER(C.c_int)), ("tracers", _dptr),
@@ -153,6 +158,7 @@ PROTOTYPES = {
     "obgc_dms_source_sink": (C.c_int, [C.c_void_p, C.POINTER(DmsSourceSinkArgs)]),
     "obgc_dms_surface_fluxes": (C.c_int, [C.c_void_p, C.POINTER(DmsSurfaceFluxesArgs)]),
     "obgc_macros_source_sink": (C.c_int, [C.c_void_p, C.POINTER(MacrosSourceSinkArgs)]),
+    "obgc_apply_tendencies": (C.c_int, [C.c_void_p, C.POINTER(ApplyTendenciesArgs)]),
     "obgc_synth_fill": (C.c_int, [C.c_void_p, C.POINTER(SynthArgs)]),
 }
 

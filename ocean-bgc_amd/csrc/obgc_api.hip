@@ -826,6 +826,31 @@ extern "C" int obgc_macros_source_sink(obgc_handle* h, const obgc_macros_source_
   return finish(h, st.host);
 }
 
+// ============================================================================ resident tracers ==
+
+extern "C" int obgc_apply_tendencies(obgc_handle* h, const obgc_apply_tendencies_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.memspace != OBGC_MEM_DEVICE)
+    return fail(h, OBGC_ERR_UNSUPPORTED, "obgc_apply_tendencies: tracers must be resident on the device (OBGC_MEM_DEVICE)");
+  if (a->ntracer < 0 || !a->tracers || !a->tend || !a->kmax || (a->net_flux && !a->dz))
+    return fail(h, OBGC_ERR_INVALID, "obgc_apply_tendencies: null array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(a->grid);
+  if (v.ncol == 0 || a->ntracer == 0) return OBGC_OK;
+  h->timed_valid = false;
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  launch_apply_tendencies(v, a->ntracer, a->tracers, a->tend, a->net_flux, a->dz, a->kmax, a->dt, a->clamp_nonneg, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+  return finish(h, false);
+}
+
 // ================================================================================= synth ==
 
 extern "C" int obgc_synth_fill(obgc_handle* h, const obgc_synth_args* a) {

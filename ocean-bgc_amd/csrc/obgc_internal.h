@@ -115,6 +115,8 @@ void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s)
 void launch_dms_surface(const DmsSurfKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
 void launch_macros(const MacrosKernelArgs& a, const obgc_macros_params& p, hipStream_t s);
 void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s);
+void launch_apply_tendencies(const GridView& g, int ntracer, double* x, const double* t, const double* nf, const double* dz,
+                             const int* kmax, double dt, int clamp, hipStream_t s);
 // LDS-tiled transposes between the reference's KFAST order and the native COLFAST order
 // for `nplanes` planes: src/dst element strides as in GridView.
 void launch_transpose_k2c(const double* src, double* dst, int nlev, int ncol, long long src_ld,

@@ -205,6 +205,22 @@ class Engine:
             a.diag = C.pointer(d)
         self._check(self.lib.obgc_macros_source_sink(self.h, C.byref(a)), "obgc_macros_source_sink")
 
+    def apply_tendencies(self, nlev, ncol, layout, tracers, tend, kmax, dt, net_flux=None, dz=None, clamp_nonneg=False,
+                         ld=0, plane=0, ldc=0):
+        """x <- x + dt*(tend + [k==1]*net_flux/dz) on device-resident tracers."""
+        ms = self._memspace(tracers)
+        a = L.ApplyTendenciesArgs()
+        a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        a.ntracer = int(tracers.shape[0])
+        vals = dict(tracers=tracers, tend=tend, kmax=kmax)
+        names = ["tracers", "tend", "kmax"]
+        if net_flux is not None:
+            vals.update(net_flux=net_flux, dz=dz)
+            names += ["net_flux", "dz"]
+        self._fill(a, names, vals, ms)
+        a.dt, a.clamp_nonneg = float(dt), 1 if clamp_nonneg else 0
+        self._check(self.lib.obgc_apply_tendencies(self.h, C.byref(a)), "obgc_apply_tendencies")
+
     def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, **dev_arrays):
         """Fill device tensors (native COLFAST layout) with the synthetic workload."""
         a = L.SynthArgs()

@@ -158,6 +158,19 @@ class ColumnEngine:
         return dict(forcing={nm: dn(v, "c") for nm, v in f.items()}, netFlux=dn(netf, "c"),
                     fdiag={nm: dn(v, "c") for nm, v in fd.items()})
 
+    # ---- resident tracers (no reference routine) ----
+    def apply_tendencies(self, tracers, tend, kmax, dt, net_flux=None, dz=None, clamp_nonneg=False):
+        """Returns x + dt*(tend + [k==1]*net_flux/dz) computed on the device (device paths only)."""
+        if self.path == "host":
+            raise ValueError("apply_tendencies needs a device path: the point is tracers that stay on the GPU")
+        n, nc, nz = tracers.shape
+        up = self._up
+        x = up(tracers, "kc")
+        self.eng.apply_tendencies(nz, nc, self._layout, x, up(tend, "kc"), up(np.asarray(kmax, dtype=np.int32), "c"), dt,
+                                  None if net_flux is None else up(net_flux, "c"), None if dz is None else up(dz, "kc"),
+                                  clamp_nonneg)
+        return self._down(x, "kc")
+
     # ---- MACROS (MACROS_mod.F90:137) ----
     def MACROS_SourceSink(self, tracers, kmax, diag_init=0.0):
         n, nc, nz = tracers.shape

@@ -1605,3 +1605,21 @@ void ora_macros_source_sink(const ora_macros_params *p, int nz, int nc, const do
 #undef TRM
 #undef DK
 }
+
+/* SURVEY.md 8f rank 2 (no reference counterpart; see obgc_oracle.h) */
+void ora_apply_tendencies(int nz, int nc, int ntracer, double *tracers, const double *tend, const double *net_flux,
+                          const double *dz, const int *kmax, double dt, int clamp_nonneg) {
+  const size_t plane = (size_t)nz * nc;
+  for (int n = 0; n < ntracer; ++n)
+    for (int c = 0; c < nc; ++c) {
+      int km = kmax[c] < nz ? kmax[c] : nz;
+      for (int k = 0; k < km; ++k) {
+        const size_t ix = (size_t)n * plane + (size_t)c * nz + k;
+        double s = tend[ix];
+        if (k == 0 && net_flux) s = s + net_flux[(size_t)n * nc + c] / dz[(size_t)c * nz];
+        double v = tracers[ix] + dt * s;
+        if (clamp_nonneg && !(v > 0.0)) v = 0.0;
+        tracers[ix] = v;
+      }
+    }
+}

@@ -198,6 +198,21 @@ class Oracle:
         return dict(forcing={nm: frc[i] for i, nm in enumerate(F.DMS_SURF_FORCING)}, netFlux=netf,
                     fdiag={nm: fd[i] for i, nm in enumerate(F.DMS_FLUX_DIAG)})
 
+    def apply_tendencies(self, tracers, tend, kmax, dt, net_flux=None, dz=None, clamp_nonneg=False):
+        """x + dt*(tend + [k==1]*net_flux/dz); returns the updated copy (parity unpinned: no reference routine)."""
+        n, nc, nz = tracers.shape
+        x = np.ascontiguousarray(tracers, dtype=np.float64).copy()
+        fn = self.lib.ora_apply_tendencies
+        vp = C.c_void_p
+        fn.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, vp, vp, _ip, C.c_double, C.c_int]
+        fn.restype = None
+        nf = np.ascontiguousarray(net_flux, dtype=np.float64) if net_flux is not None else None
+        dzc = np.ascontiguousarray(dz, dtype=np.float64) if dz is not None else None
+        fn(nz, nc, n, x, np.ascontiguousarray(tend, dtype=np.float64), nf.ctypes.data_as(vp) if nf is not None else None,
+           dzc.ctypes.data_as(vp) if dzc is not None else None, np.ascontiguousarray(kmax, dtype=np.int32), float(dt),
+           1 if clamp_nonneg else 0)
+        return x
+
     def macros_source_sink(self, tracers, kmax, diag_init=0.0):
         n, nc, nz = tracers.shape
         tend = np.full((8, nc, nz), diag_init)

@@ -1,0 +1,96 @@
+"""explicit update of device-resident tracers (obgc_apply_tendencies).
+
+There is no reference routine for this step (the host model integrates in time), so the oracle function is the
+plain statement of the formula in include/obgc.h -- "parity unpinned" by construction.  What is pinned:
+bit-exact agreement of the HIP kernel with that statement (fp64, no contraction), both layouts, and the
+properties of the update (untouched cells, dt = 0 identity, additivity in dt for exactly representable data).
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+
+@pytest.fixture(scope="module")
+def engines(pkg):
+    if not has_gpu():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False (no CPU fallback exists)")
+    from ocean_bgc_amd.modules import ColumnEngine
+    return {p: ColumnEngine(0, path=p) for p in ("device_colfast", "device_kfast")}
+
+
+def _case(synth, nc, nz, col0):
+    syn = synth.generate(nc, nz, col0=col0)
+    tr = synth.bgc_tracer_array(syn)
+    rng = np.random.default_rng(7)
+    tend = rng.standard_normal(tr.shape) * 1e-6 * np.abs(tr).max(axis=(1, 2), keepdims=True)
+    net = rng.standard_normal((30, nc)) * 1e-4
+    return syn, tr, tend, net
+
+
+def test_oracle_statement_of_the_update(oracle, synth):
+    """CPU: the oracle function against a direct numpy evaluation, and the properties of the formula."""
+    nc, nz = 37, 12
+    syn, tr, tend, net = _case(synth, nc, nz, 5)
+    dt = 1800.0
+    got = oracle.apply_tendencies(tr, tend, syn["kmax"], dt, net, syn["dz"])
+    s = tend.copy()
+    s[:, :, 0] = tend[:, :, 0] + net / syn["dz"][None, :, 0]
+    want = tr + dt * s
+    active = (np.arange(nz)[None, :] < syn["kmax"][:, None])[None]
+    want = np.where(active, want, tr)
+    assert np.array_equal(got, want)
+    assert np.array_equal(oracle.apply_tendencies(tr, tend, syn["kmax"], 0.0, net, syn["dz"]), tr)
+    clamped = oracle.apply_tendencies(tr, -np.abs(tend) * 1e9, syn["kmax"], dt, clamp_nonneg=True)
+    assert (clamped[np.broadcast_to(active, tr.shape)] >= 0.0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["device_colfast", "device_kfast"])
+def test_gpu_update_is_bit_exact(engines, oracle, synth, path):
+    E = engines[path]
+    nc, nz = 3000, 60
+    syn, tr, tend, net = _case(synth, nc, nz, 99)
+    for dt, clamp, use_flux in ((3600.0, False, True), (1800.0, True, True), (600.0, False, False), (0.0, False, True)):
+        nf, dz = (net, syn["dz"]) if use_flux else (None, None)
+        t = -np.abs(tend) * 1e7 if clamp else tend
+        got = E.apply_tendencies(tr, t, syn["kmax"], dt, nf, dz, clamp)
+        want = oracle.apply_tendencies(tr, t, syn["kmax"], dt, nf, dz, clamp)
+        assert np.array_equal(got, want), (path, dt, clamp, np.abs(got - want).max())
+    # cells below the sea floor keep their bits, land columns entirely
+    below = (np.arange(nz)[None, :] >= syn["kmax"][:, None])
+    got = E.apply_tendencies(tr, tend, syn["kmax"], 3600.0, net, syn["dz"])
+    assert np.array_equal(got[:, below], tr[:, below])
+
+
+@pytest.mark.gpu
+def test_resident_step_sequence_matches_oracle(engines, oracle, synth):
+    """Three steps of SurfaceFluxes -> SourceSink -> apply with the tracers fed back, against the same sequence
+    on the oracle: tendencies meet the parity bars at every step although the states have drifted apart by ulps."""
+    import parity as P
+    E = engines["device_colfast"]
+    nc, nz, dt = 512, 60, 900.0
+    syn = synth.generate(nc, nz, col0=2024)
+    xg = synth.bgc_tracer_array(syn)
+    xo = xg.copy()
+    f = syn["forcing"]
+    flux = [syn[nm] for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")]
+    phg = [np.zeros((nc, nz)), np.zeros((nc, nz))]
+    pho = [np.zeros((nc, nz)), np.zeros((nc, nz))]
+    fg, fo = dict(f), dict(f)
+    for step in range(3):
+        sg = E.BGC_SurfaceFluxes(xg, fg, *flux)
+        so = oracle.bgc_surface_fluxes(xo, fo, *flux)
+        a = (syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+             syn["sw"])
+        wg = E.BGC_SourceSink(xg, *a, *phg, diagnostics=False)
+        wo = oracle.bgc_source_sink(xo, *a, *pho, diagnostics=False)
+        rep = P.Report()
+        P.compare_tend(rep, "step%d" % step, wg["tend"], wo["tend"])
+        assert rep.ok(), "\n".join(rep.fail[:5])
+        xg = E.apply_tendencies(xg, wg["tend"], syn["kmax"], dt, sg["netFlux"], syn["dz"], True)
+        xo = oracle.apply_tendencies(xo, wo["tend"], syn["kmax"], dt, so["netFlux"], syn["dz"], True)
+        assert P.e_norm(xg, xo) < 1e-12
+        phg, pho = [wg["ph_prev"], wg["ph_prev_alt"]], [wo["ph_prev"], wo["ph_prev_alt"]]
+        for nm in ("surface_pH", "surface_pH_alt_co2"):
+            fg[nm], fo[nm] = sg["forcing"][nm], so["forcing"][nm]
