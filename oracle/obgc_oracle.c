@@ -10,6 +10,19 @@
 #include <math.h>
 #include <string.h>
 
+/* Branch counters (SURVEY.md 8d "branches the data must hit"): every BR() marks one arm of a data-dependent
+ * branch of the reference; tests assert that the synthetic workload reaches all of them.  Thread-local, so the
+ * restatement stays re-entrant. */
+enum { BR_zero_mask, BR_gQfe_limited, BR_gQsi_fe_limited, BR_gQsi_fe_zero, BR_gQsi_si_limited, BR_kpar_low, BR_kpar_high, BR_ph_cold, BR_ph_warm, BR_zsat_found, BR_zsat_never, BR_q10_below_thres, BR_mmrt_north, BR_mmrt_south, BR_caco3_cold, BR_caco3_bloom, BR_zumax_taper_north, BR_zumax_taper_south, BR_par_avg_dark, BR_fe_scav_high, BR_nitrif_active, BR_nitrif_taper, BR_o2_lt5, BR_o2_5_40, BR_scalelen_top, BR_scalelen_mid, BR_scalelen_deep, BR_qa_def_consumed, BR_qa_def_remains, BR_poc_hflux_zero, BR_iron_clamp, BR_bottom_flux, BR_bottom_no3_lt5, BR_bottom_o2_lt1, BR_bottom_sio2_fast, BR_bottom_above_lysocline, BR_newton_bracket_grow, BR_newton_bisect, BR_newton_step, BR_newton_exit_same, BR_newton_exit_xacc, BR_COUNT };
+static _Thread_local unsigned long long ora_branch_hits[BR_COUNT];
+static const char *const ora_branch_names[BR_COUNT] = {"zero_mask", "gQfe_limited", "gQsi_fe_limited", "gQsi_fe_zero", "gQsi_si_limited", "kpar_low", "kpar_high", "ph_cold", "ph_warm", "zsat_found", "zsat_never", "q10_below_thres", "mmrt_north", "mmrt_south", "caco3_cold", "caco3_bloom", "zumax_taper_north", "zumax_taper_south", "par_avg_dark", "fe_scav_high", "nitrif_active", "nitrif_taper", "o2_lt5", "o2_5_40", "scalelen_top", "scalelen_mid", "scalelen_deep", "qa_def_consumed", "qa_def_remains", "poc_hflux_zero", "iron_clamp", "bottom_flux", "bottom_no3_lt5", "bottom_o2_lt1", "bottom_sio2_fast", "bottom_above_lysocline", "newton_bracket_grow", "newton_bisect", "newton_step", "newton_exit_same", "newton_exit_xacc"};
+#define BR(n) (ora_branch_hits[BR_##n]++)
+int ora_branch_count(void) { return BR_COUNT; }
+const char *ora_branch_name(int i) { return (i >= 0 && i < BR_COUNT) ? ora_branch_names[i] : ""; }
+unsigned long long ora_branch_hit(int i) { return (i >= 0 && i < BR_COUNT) ? ora_branch_hits[i] : 0; }
+void ora_branch_reset(void) { memset(ora_branch_hits, 0, sizeof ora_branch_hits); }
+
+
 /* ------------------------------------------------------------------ helpers */
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 static inline double dmin(double a, double b) { return a < b ? a : b; }
@@ -365,6 +378,7 @@ static double drtsafe_row(const co3_state *s, double k1, double k2, double x1, d
     talk_row(s, k1, k2, x2, &fhi, &df);
     int mask = (flo > 0.0 && fhi > 0.0) || (flo < 0.0 && fhi < 0.0);
     if (!mask) break;
+    BR(newton_bracket_grow);
     dx = sqrt(x2 / x1);
     x2 = x2 * dx;
     x1 = x1 / dx;
@@ -383,14 +397,18 @@ static double drtsafe_row(const co3_state *s, double k1, double k2, double x1, d
       dxold = dx;
       dx = 0.5 * (xhi - xlo);
       soln = xlo + dx;
+      BR(newton_bisect);
       if (xlo == soln) mask = 0;
     } else {
       dxold = dx;
       dx = -f / df;
       temp = soln;
       soln = soln + dx;
+      BR(newton_step);
       if (temp == soln) mask = 0;
     }
+    if (!mask) BR(newton_exit_same);
+    else if (fabs(dx) < xacc_) BR(newton_exit_xacc);
     if (fabs(dx) < xacc_) mask = 0;
     if (!mask) return soln;
     talk_row(s, k1, k2, soln, &f, &df);
@@ -596,6 +614,7 @@ static void compute_particulate_terms(const ora_bgc_params *p, int isbottom, sin
   dust->sed_loss = 0.0; *SED_DENITRIF = 0.0; *OTHER_REMIN = 0.0;
   /* 2273-2286 */
   const double *sz = p->parm_scalelen_z, *sv = p->parm_scalelen_vals;
+  if (cell_bottom_depth < sz[0]) BR(scalelen_top); else if (cell_bottom_depth >= sz[3]) BR(scalelen_deep); else BR(scalelen_mid);
   if (cell_bottom_depth < sz[0]) scalelength = sv[0];
   else if (cell_bottom_depth >= sz[3]) scalelength = sv[3];
   else {
@@ -614,6 +633,7 @@ static void compute_particulate_terms(const ora_bgc_params *p, int isbottom, sin
   double dzr_loc = 1.0 / dz_loc;
   double poc_diss = POC->diss, sio2_diss = P_SiO2->diss, caco3_diss = P_CaCO3->diss, dust_diss = dust->diss;
   /* 2311-2315 */
+  if ((O2_loc >= 5.0) && (O2_loc < 40.0)) BR(o2_5_40); else if (O2_loc < 5.0) BR(o2_lt5);
   if ((O2_loc >= 5.0) && (O2_loc < 40.0)) poc_diss = POC->diss * (1.0 + (3.3 - 1.0) * (40.0 - O2_loc) / 35.0);
   else if (O2_loc < 5.0) poc_diss = POC->diss * 3.3;
   /* 2321-2330 */
@@ -646,6 +666,7 @@ static void compute_particulate_terms(const ora_bgc_params *p, int isbottom, sin
     new_QA_dust_def = 0.0;
   if (new_QA_dust_def > 0.0) {
     new_QA_dust_def = new_QA_dust_def - POC_PROD_avail * dz_loc;
+    if (new_QA_dust_def < 0.0) BR(qa_def_consumed); else BR(qa_def_remains);
     if (new_QA_dust_def < 0.0) {
       POC_PROD_avail = -new_QA_dust_def * dzr_loc;
       new_QA_dust_def = 0.0;
@@ -655,6 +676,7 @@ static void compute_particulate_terms(const ora_bgc_params *p, int isbottom, sin
   }
   *QA_dust_def = new_QA_dust_def;
   /* 2423-2438 */
+  if (POC->hflux_in == 0.0 && POC->prod == 0.0) BR(poc_hflux_zero);
   if (POC->hflux_in == 0.0 && POC->prod == 0.0) {
     POC->hflux_out = 0.0;
   } else {
@@ -678,6 +700,7 @@ static void compute_particulate_terms(const ora_bgc_params *p, int isbottom, sin
     P_iron->remin = (POC->remin * (P_iron->sflux_in + P_iron->hflux_in) / (POC->sflux_in + POC->hflux_in));
   P_iron->remin = P_iron->remin + (P_iron->sflux_in * 1.5e-5);
   P_iron->sflux_out = P_iron->sflux_in + dz_loc * ((1.0 - P_iron->gamma) * P_iron->prod - P_iron->remin);
+  if (P_iron->sflux_out < 0.0) BR(iron_clamp);
   if (P_iron->sflux_out < 0.0) {
     P_iron->sflux_out = 0.0;
     P_iron->remin = P_iron->sflux_in * dzr_loc + (1.0 - P_iron->gamma) * P_iron->prod;
@@ -689,22 +712,27 @@ static void compute_particulate_terms(const ora_bgc_params *p, int isbottom, sin
   if (isbottom) {                                                     /* 2522-2631 */
     double flux = POC->sflux_out + POC->hflux_out, flux_alt;
     if (flux > 0.0) {
+      BR(bottom_flux);
       flux_alt = flux * mpercm * SPD;
       POC->sed_loss = flux * dmin(0.8, p->parm_POMbury * (0.013 + 0.53 * flux_alt * flux_alt /
                                                             ((7.0 + flux_alt) * (7.0 + flux_alt))));
       *SED_DENITRIF = dzr_loc * flux * (0.06 + 0.19 * pow(0.99, (O2_loc - NO3_loc)));
+      if (NO3_loc < 5.0) BR(bottom_no3_lt5);
       if (NO3_loc < 5.0) *SED_DENITRIF = 0.;
       flux_alt = flux * 1.0e-6 * SPD * 365.0;
       *OTHER_REMIN = dzr_loc * dmin(dmin(0.1 + flux_alt, 0.5) * (flux - POC->sed_loss),
                                     (flux - POC->sed_loss - (*SED_DENITRIF * dz_loc * denitrif_C_N)));
+      if (O2_loc < 1.0) BR(bottom_o2_lt1);
       if (O2_loc < 1.0)
         *OTHER_REMIN = dzr_loc * (flux - POC->sed_loss - (*SED_DENITRIF * dz_loc * denitrif_C_N));
     }
     flux = P_SiO2->sflux_out + P_SiO2->hflux_out;
     flux_alt = flux * mpercm * SPD;
+    if (flux_alt > 2.0) BR(bottom_sio2_fast);
     if (flux_alt > 2.0) P_SiO2->sed_loss = 0.2;
     else P_SiO2->sed_loss = 0.04;
     P_SiO2->sed_loss = flux * p->parm_BSIbury * P_SiO2->sed_loss;
+    if (cell_bottom_depth < 3300.0e2) BR(bottom_above_lysocline);
     if (cell_bottom_depth < 3300.0e2) {
       flux = P_CaCO3->sflux_out + P_CaCO3->hflux_out;
       P_CaCO3->sed_loss = flux;
@@ -806,6 +834,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       for (int a = 0; a < 4; ++a) {
         int zero_mask = aChl[a] == 0.0 || aC[a] == 0.0 || aFe[a] == 0.0;
         if (at[a].Si_ind > 0) zero_mask = zero_mask || aSi[a] == 0.0;
+        if (zero_mask) BR(zero_mask);
         if (zero_mask) { aChl[a] = 0.0; aC[a] = 0.0; aFe[a] = 0.0; }
         if (at[a].Si_ind > 0) { if (zero_mask) aSi[a] = 0.0; }
         if (at[a].CaCO3_ind > 0) { if (zero_mask) aCaCO3[a] = 0.0; }
@@ -821,14 +850,14 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       for (int a = 0; a < 4; ++a) {
         gQfe[a] = at[a].gQfe_0;
         if (Fe_loc < cks * at[a].kFe)
-          gQfe[a] = dmax((gQfe[a] * Fe_loc / (cks * at[a].kFe)), at[a].gQfe_min);
+          { BR(gQfe_limited); gQfe[a] = dmax((gQfe[a] * Fe_loc / (cks * at[a].kFe)), at[a].gQfe_min); }
         if (at[a].Si_ind > 0) {
           gQsi[a] = gQsi_0;
           if ((Fe_loc < cksi * at[a].kFe) && (Fe_loc > 0.0) && (SiO3_loc > (cksi * at[a].kSiO3)))
-            gQsi[a] = dmin((gQsi[a] * cksi * at[a].kFe / Fe_loc), gQsi_max);
-          if (Fe_loc == 0.0) gQsi[a] = gQsi_max;
+            { BR(gQsi_fe_limited); gQsi[a] = dmin((gQsi[a] * cksi * at[a].kFe / Fe_loc), gQsi_max); }
+          if (Fe_loc == 0.0) { BR(gQsi_fe_zero); gQsi[a] = gQsi_max; }
           if (SiO3_loc < (cksi * at[a].kSiO3))
-            gQsi[a] = dmax((gQsi[a] * SiO3_loc / (cksi * at[a].kSiO3)), gQsi_min);
+            { BR(gQsi_si_limited); gQsi[a] = dmax((gQsi[a] * SiO3_loc / (cksi * at[a].kSiO3)), gQsi_min); }
         }
         if (at[a].CaCO3_ind > 0) {
           QCaCO3[a] = aCaCO3[a] / (aC[a] + epsC);
@@ -839,6 +868,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       double PAR_in = PAR_out;
       double work1 = dmax(((aChl[0] + aChl[1]) + aChl[2]) + aChl[3], 0.02);
       double KPARdz;
+      if (work1 < 0.13224) BR(kpar_low); else BR(kpar_high);
       if (work1 < 0.13224) KPARdz = 0.000919 * pow(work1, 0.3536);
       else KPARdz = 0.001131 * pow(work1, 0.4562);
       KPARdz = KPARdz * dz;
@@ -847,6 +877,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
 
       /* 940-1001: carbonate chemistry (NB 975: the ALT solve is fed DIC_loc) */
       double work2, work3 = 0.0, work4 = 0.0, work5, H2CO3, HCO3, CO3, H2CO3_ALT, HCO3_ALT, CO3_ALT;
+      if (ph_prev[ix] != 0.0) BR(ph_warm); else BR(ph_cold);
       if (ph_prev[ix] != 0.0) { work1 = ph_prev[ix] - del_ph; work2 = ph_prev[ix] + del_ph; }
       else { work1 = phlo_3d_init; work2 = phhi_3d_init; }
       work5 = zc * 0.01;
@@ -878,6 +909,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       }
       CO3_CALC_ANOM_km1 = CO3 - work1;
       CO3_ARAG_ANOM_km1 = CO3 - work2;
+      if (k == kmax - 1 && k > 0) { if (ZSATCALC == zb) BR(zsat_never); else if (ZSATCALC > 0.0) BR(zsat_found); }
       if (k == kmax - 1) { CC(zsatcalc, c) = ZSATCALC; CC(zsatarag, c) = ZSATARAG; }
 
       /* 1041 */
@@ -893,6 +925,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       for (int a = 0; a < 4; ++a) {
         C_loss_thres = f_loss_thres * at[a].loss_thres;
         if (at[a].temp_function == tfnc_q10) {
+          if (T < at[a].temp_thres) BR(q10_below_thres);
           if (T < at[a].temp_thres) C_loss_thres = f_loss_thres * at[a].loss_thres2;
         } else if (at[a].temp_function == tfnc_quasi_mmrt) {
           tmpTmax = (lat[c] >= 0.0) ? at[a].temp_thresN : at[a].temp_thresS;
@@ -931,6 +964,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
         double PCmax = at[a].PCref * f_nut * Tfunc;
         if (T < at[a].temp_thres) PCmax = 0.0;
         if (at[a].temp_function == tfnc_quasi_mmrt) {
+          if (lat[c] >= 0.0) BR(mmrt_north); else BR(mmrt_south);
           if (lat[c] >= 0.0) { tmpTopt = at[a].temp_optN; tmpTmax = at[a].temp_thresN; }
           else { tmpTopt = at[a].temp_optS; tmpTmax = at[a].temp_thresS; }
           PCmax = PCmax * dmin(1.0, ((tmpTmax - T) / (tmpTmax - tmpTopt)));
@@ -974,6 +1008,8 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
         if (at[a].imp_calcifier) {
           CaCO3_PROD[a] = p->parm_f_prod_sp_CaCO3 * photoC[a];
           CaCO3_PROD[a] = CaCO3_PROD[a] * f_nut;
+          if (T < CaCO3_temp_thres1) BR(caco3_cold);
+          if (aC[a] > CaCO3_sp_thres) BR(caco3_bloom);
           if (T < CaCO3_temp_thres1)
             CaCO3_PROD[a] = CaCO3_PROD[a] * dmax((T - CaCO3_temp_thres2), 0.0) / (CaCO3_temp_thres1 - CaCO3_temp_thres2);
           if (aC[a] > CaCO3_sp_thres)
@@ -994,6 +1030,8 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
           if (at[a2].grazee_ind == at[a].grazee_ind) work1 = work1 + Pprime[a2];
         double z_umax = at[a].z_umax_0 * Tfunc;
         if (a + 1 == p->diat_ind) {
+          if ((lat[c] >= 0.0) && (T > at[a].temp_optN)) BR(zumax_taper_north);
+          else if ((lat[c] <= 0.0) && (T > at[a].temp_optS)) BR(zumax_taper_south);
           if ((lat[c] >= 0.0) && (T > at[a].temp_optN))
             z_umax = z_umax * dmax((at[a].temp_thresN - T) / (at[a].temp_thresN - at[a].temp_optN), 0.95);
           else if ((lat[c] <= 0.0) && (T > at[a].temp_optS))
@@ -1064,6 +1102,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       double DOFe_remin = DOFe_loc * DOFe_reminR;
       double DOP_remin = DOP_loc * DOP_reminR;
       double DONr_remin, DOPr_remin;
+      if (!(PAR_avg > 1.0)) BR(par_avg_dark);
       if (PAR_avg > 1.0) {
         DONr_remin = DONr_loc * DONr_reminR;
         DOPr_remin = DOPr_loc * DOPr_reminR;
@@ -1091,6 +1130,7 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
                                              (P_CaCO3.sflux_out + P_CaCO3.hflux_out) * P_CaCO3.mass +
                                              (P_SiO2.sflux_out + P_SiO2.hflux_out) * P_SiO2.mass +
                                              (dust.sflux_out + dust.hflux_out) * dust_fescav_scale);
+      if (Fe_loc > fe_scavenge_thres1) BR(fe_scav_high);
       if (Fe_loc > fe_scavenge_thres1)
         Fe_scavenge_rate = Fe_scavenge_rate + (Fe_loc - fe_scavenge_thres1) * fe_max_scale2;
       double Fe_scavenge = YPS * Fe_loc * Fe_scavenge_rate;
@@ -1132,6 +1172,8 @@ void ora_bgc_source_sink(const ora_bgc_params *p, int nz, int nc, const double *
       double NITRIF;
       if (PAR_out < p->parm_nitrif_par_lim) {
         NITRIF = p->parm_kappa_nitrif * NH4_loc;
+        BR(nitrif_active);
+        if (PAR_in > p->parm_nitrif_par_lim) BR(nitrif_taper);
         if (PAR_in > p->parm_nitrif_par_lim) NITRIF = NITRIF * log(PAR_out / p->parm_nitrif_par_lim) / (-KPARdz);
       } else NITRIF = 0.0;
       KC(NITRIF, k, c) = NITRIF;

@@ -202,6 +202,12 @@ void ora_dms_surface_fluxes(const ora_dms_params *p, int nz, int nc, const doubl
 void ora_macros_source_sink(const ora_macros_params *p, int nz, int nc, const double *tracers,
                             const int *kmax, double *tend, double *dkc);
 
+/* branch-coverage counters of the BGC_SourceSink / co2calc restatement (thread-local; see obgc_oracle.c) */
+int ora_branch_count(void);
+const char *ora_branch_name(int i);
+unsigned long long ora_branch_hit(int i);
+void ora_branch_reset(void);
+
 /* SURVEY.md 8f rank 2, explicit update of resident tracers.  PARITY UNPINNED: the reference has no such routine
  * (the host model integrates in time); this is the plain statement of the formula in include/obgc.h, in the
  * reference's array layout:  x(k,c,n) += dt*(tend(k,c,n) + [k==1]*net_flux(c,n)/dz(1,c)),  k <= kmax(c). */

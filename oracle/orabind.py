@@ -198,6 +198,15 @@ class Oracle:
         return dict(forcing={nm: frc[i] for i, nm in enumerate(F.DMS_SURF_FORCING)}, netFlux=netf,
                     fdiag={nm: fd[i] for i, nm in enumerate(F.DMS_FLUX_DIAG)})
 
+    # ---- branch-coverage counters ----------------------------------
+    def branch_reset(self):
+        self.lib.ora_branch_reset()
+
+    def branch_hits(self):
+        self.lib.ora_branch_name.restype = C.c_char_p
+        self.lib.ora_branch_hit.restype = C.c_ulonglong
+        return {self.lib.ora_branch_name(i).decode(): int(self.lib.ora_branch_hit(i)) for i in range(self.lib.ora_branch_count())}
+
     def apply_tendencies(self, tracers, tend, kmax, dt, net_flux=None, dz=None, clamp_nonneg=False):
         """x + dt*(tend + [k==1]*net_flux/dz); returns the updated copy (parity unpinned: no reference routine)."""
         n, nc, nz = tracers.shape

@@ -70,7 +70,7 @@ def compare_tend(rep, name, got, want):
         rep.note("tend_e_pt", "%s[%d]" % (name, i), e_pt(got[i], want[i]), TOL_TEND_PT)
 
 
-def compare_bgc(got, want, rep=None, diagnostics=True):
+def compare_bgc(got, want, rep=None, diagnostics=True, dz=None):
     rep = rep or Report()
     compare_tend(rep, "bgc.tend", got["tend"], want["tend"])
     rep.note("ph", "ph_prev", e_norm(got["ph_prev"], want["ph_prev"]), TOL_PH)
@@ -81,6 +81,10 @@ def compare_bgc(got, want, rep=None, diagnostics=True):
         for nm, w in want[grp].items():
             rep.note("diag", grp + "." + nm, e_norm(got[grp][nm], w), TOL_DIAG)
     scale = np.abs(want["c"]["photoC_TOT_zint"]).max() + np.abs(want["c"]["tot_CaCO3_form_zint"]).max() + 1e-300
+    if dz is not None:
+        # the integrand itself: sum over levels of dz * |tendencies| (needed when the carbon turnover of a column is
+        # not tied to its photosynthesis, e.g. a dark bloom in tests/crafted.py)
+        scale = max(scale, (np.abs(want["tend"]).sum(axis=0) * np.asarray(dz)).sum(axis=1).max())
     for nm, w in want["c"].items():
         g = got["c"][nm]
         if nm in EXACT_C:
