@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--diag", default="full", choices=("full", "none"),
                     help="full: all 96 diagnostics written like the reference does; none: tendencies + pH state only")
+    ap.add_argument("--ph", default="cold", choices=("cold", "warm"),
+                    help="cold (headline): PH_PREV_* = 0 at every step, full [6, 9] bracket; warm (secondary timing of "
+                         "SURVEY.md 8d): the previous step's pH is the bracket centre, as in a running model")
     ap.add_argument("--columns", type=int, default=0, help="override columns per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -200,7 +203,7 @@ def main():
     eng.synth_fill(nz, ncol, col0, tracers=tr, kmax=kmax, **kc, **cc)
     tend = torch.empty((30, nz, ncol), **f64)
     # cold start per step: a zeroed pH state pair per step, rotated over at most 8 buffers
-    nbuf = max(1, min(args.steps, 8))
+    nbuf = 1 if args.ph == "warm" else max(1, min(args.steps, 8))
     ph = [torch.zeros((2, nz, ncol), **f64) for _ in range(nbuf)]
     diag = None
     if diag_on:
@@ -281,12 +284,15 @@ def main():
     torch.cuda.synchronize()              # inputs were produced on torch's stream / the engine's stream
     for i in range(args.warmup):
         step(i, False)
-    rezero()
+    if args.ph == "cold":
+        rezero()
+    elif args.warmup == 0:
+        step(0, False)                    # a warm measurement needs one untimed call to have a previous pH
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)                     # engine calls are synchronous: each returns with its kernels done
-        if (i + 1) % nbuf == 0 and i + 1 < args.steps:
+        if args.ph == "cold" and (i + 1) % nbuf == 0 and i + 1 < args.steps:
             rezero()                      # keeps every timed step cold; 2 small memsets per 8 steps, inside the timing
     barrier()
     elapsed = time.perf_counter() - t0
@@ -329,8 +335,9 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s: %d columns x %d levels per GPU, %s, native column-fastest layout, "
-                                      "diagnostics=%s, cold pH bracket every step"
-                                      % (args.config, ncol, nz, "+".join(modules), dk),
+                                      "diagnostics=%s, %s"
+                                      % (args.config, ncol, nz, "+".join(modules), dk,
+                                         "cold pH bracket every step" if args.ph == "cold" else "warm pH brackets (previous step)"),
                           "columns_per_gpu": ncol, "levels": nz, "active_cells_per_gpu": active_cells,
                           "updates_per_step_all_gpus": updates_all, "parallelism": "column-range x%d, no collective" % world,
                           "columns_per_s": ncol * world * args.steps / elapsed,
