@@ -646,18 +646,33 @@ struct LevelIn {
 template <bool DIAG>
 __device__ __forceinline__ void load_level(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, LevelIn<DIAG>& L) {
   const long long pl = A.g.plane, sp = A.splane;
-#define TRC(slot) dmax(0.0, A.tracers[(long long)((slot)-1) * pl + ix])
+#define RAWT(slot) A.tracers[(long long)((slot)-1) * pl + ix]
 #define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
 #define SCR(s) A.scratch[(long long)(s) * sp + ix]
   L.dz = A.dz[ix]; L.zb = A.zbot[ix]; L.fesed = A.fesed[ix]; L.T = A.temp[ix];
-  L.NO3 = TRC(P.ind[1]); L.Fe = TRC(P.ind[4]); L.O2 = TRC(P.ind[5]);
+  // raw values: the clamps (747-752) are applied where the level is evaluated -- a dmax() here would make the wave wait
+  // for these loads right after issuing them and put a memory round trip back into every level of the chain
+  L.NO3 = RAWT(P.ind[1]); L.Fe = RAWT(P.ind[4]); L.O2 = RAWT(P.ind[5]);
   L.prodPOC = SCR(S_PRODPOC); L.prodCa = SCR(S_PRODCA); L.prodSi = SCR(S_PRODSI); L.PfeLoc = SCR(S_PFELOC);
   L.L_no3 = TEND(P.ind[1]); L.L_nh4 = TEND(P.ind[3]); L.L_fe = TEND(P.ind[4]); L.L_sio3 = TEND(P.ind[2]); L.L_po4 = TEND(P.ind[0]);
   L.L_donr = TEND(P.ind[14]); L.L_dopr = TEND(P.ind[13]); L.L_dic = TEND(P.ind[6]); L.L_alk = TEND(P.ind[8]); L.L_o2 = TEND(P.ind[5]);
   if (DIAG) { L.oc0 = SCR(S_OC0); L.d0 = SCR(S_D0); L.jc = SCR(S_JC); L.jn = SCR(S_JN); L.jp = SCR(S_JP); L.jsi = SCR(S_JSI); }
-#undef TRC
+#undef RAWT
 #undef TEND
 #undef SCR
+}
+
+// Makes the compiler retire every load of a LevelIn here.  Used once, on the first level, before the loop: otherwise
+// the wait-count state of the loop header is the merge of "first level still in flight" and "steady state", and the
+// conservative s_waitcnt it emits at the top of EVERY iteration waits for two of the just-issued prefetch loads and
+// for all stores of the previous level -- a memory round trip per level of the sequential chain.
+template <bool DIAG>
+__device__ __forceinline__ void settle(const LevelIn<DIAG>& L) {
+  asm volatile("" ::"v"(L.dz), "v"(L.zb), "v"(L.fesed), "v"(L.T), "v"(L.NO3), "v"(L.Fe), "v"(L.O2), "v"(L.prodPOC), "v"(L.prodCa),
+               "v"(L.prodSi), "v"(L.PfeLoc));
+  asm volatile("" ::"v"(L.L_no3), "v"(L.L_nh4), "v"(L.L_fe), "v"(L.L_sio3), "v"(L.L_po4), "v"(L.L_donr), "v"(L.L_dopr), "v"(L.L_dic),
+               "v"(L.L_alk), "v"(L.L_o2));
+  if (DIAG) asm volatile("" ::"v"(L.oc0), "v"(L.d0), "v"(L.jc), "v"(L.jn), "v"(L.jp), "v"(L.jsi));
 }
 
 // LANES = active lanes per wavefront (experiment knob, see launch_bgc_ecosys_sweep; 64 is the default).
@@ -685,11 +700,11 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
   double zbot_above = 0.0;
 
   LevelIn<DIAG> cur, nxt;
-  if (kmax >= 1) load_level<DIAG>(A, P, g.at(0, c), cur);
+  if (kmax >= 1) { load_level<DIAG>(A, P, g.at(0, c), cur); settle<DIAG>(cur); }
   for (int k = 0; k < kmax; ++k) {
     const long long ix = g.at(k, c);
     if (k + 1 < kmax) load_level<DIAG>(A, P, g.at(k + 1, c), nxt);   // in flight while this level is evaluated
-    const double dz = cur.dz, zb = cur.zb, NO3 = cur.NO3, Fe = cur.Fe, O2 = cur.O2;
+    const double dz = cur.dz, zb = cur.zb, NO3 = dmax(0.0, cur.NO3), Fe = dmax(0.0, cur.Fe), O2 = dmax(0.0, cur.O2);
     const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
 
     // dissolution length scales and decay factors across this level (2273-2339): functions of the inputs
