@@ -309,6 +309,19 @@ typedef struct {
 
 int obgc_apply_tendencies(obgc_handle *h, const obgc_apply_tendencies_args *a);
 
+/* --------------------------------------- diagnostics kept on the device
+ * NO reference counterpart (the host model averages and writes diagnostics).  Diagnostics are 65 % of the bytes
+ * the path produces; a host that only needs time means at its output interval keeps both the instantaneous
+ * arrays and the running means on the GPU and downloads the means it selected when the interval ends:
+ *
+ *   mean.X <- (reset ? 0 : mean.X) + weight * inst.X        for every member X non-NULL in BOTH structs
+ *
+ * over all nlev x ncol cells of (k,column[,autotroph]) members (the package zero-fills below kmax) and over ncol
+ * for (column[,autotroph]) members; padding of either layout is not touched.  weight = dt / interval.
+ * One launch for all selected members.  DEVICE pointers only; both layouts. */
+int obgc_bgc_diag_accumulate(obgc_handle *h, const obgc_grid *grid, const obgc_bgc_diag *inst,
+                             const obgc_bgc_diag *mean, double weight, int reset);
+
 /* ----------------------------------------------- workload utilities (bench/tests)
  * Deterministic synthetic columns, generated on the device in the
  * engine's native COLFAST layout for global columns [col0, col0+ncol).  Bit-identical

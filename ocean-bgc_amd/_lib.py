@@ -159,6 +159,7 @@ PROTOTYPES = {
     "obgc_dms_surface_fluxes": (C.c_int, [C.c_void_p, C.POINTER(DmsSurfaceFluxesArgs)]),
     "obgc_macros_source_sink": (C.c_int, [C.c_void_p, C.POINTER(MacrosSourceSinkArgs)]),
     "obgc_apply_tendencies": (C.c_int, [C.c_void_p, C.POINTER(ApplyTendenciesArgs)]),
+    "obgc_bgc_diag_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.POINTER(BgcDiag), C.POINTER(BgcDiag), C.c_double, C.c_int]),
     "obgc_synth_fill": (C.c_int, [C.c_void_p, C.POINTER(SynthArgs)]),
 }
 

@@ -851,6 +851,44 @@ extern "C" int obgc_apply_tendencies(obgc_handle* h, const obgc_apply_tendencies
   return finish(h, false);
 }
 
+extern "C" int obgc_bgc_diag_accumulate(obgc_handle* h, const obgc_grid* grid, const obgc_bgc_diag* inst, const obgc_bgc_diag* mean,
+                                        double weight, int reset) {
+  if (!h || !grid || !inst || !mean) return OBGC_ERR_INVALID;
+  if (!grid_ok(*grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (grid->memspace != OBGC_MEM_DEVICE)
+    return fail(h, OBGC_ERR_UNSUPPORTED, "obgc_bgc_diag_accumulate: diagnostics must be resident on the device (OBGC_MEM_DEVICE)");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(*grid);
+  if (v.ncol == 0) return OBGC_OK;
+  AccumTable planes, vecs;
+  planes.nplane = planes.nvec = vecs.nplane = vecs.nvec = 0;
+  auto add_plane = [&](const double* s, double* d) { planes.src[planes.nplane] = s; planes.dst[planes.nplane] = d; ++planes.nplane; };
+  auto add_vec = [&](const double* s, double* d) { vecs.src[vecs.nvec] = s; vecs.dst[vecs.nvec] = d; ++vecs.nvec; };
+#define KC(n) if (inst->n && mean->n) add_plane(inst->n, mean->n);
+#define KCA(n) if (inst->n && mean->n) for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) add_plane(inst->n + a * v.plane, mean->n + a * v.plane);
+#define CA(n) if (inst->n && mean->n) for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) add_vec(inst->n + a * v.ldc, mean->n + a * v.ldc);
+#define CC(n) if (inst->n && mean->n) add_vec(inst->n, mean->n);
+  OBGC_BGC_DIAG_KC(KC) OBGC_BGC_DIAG_KCA(KCA) OBGC_BGC_DIAG_CA(CA) OBGC_BGC_DIAG_C(CC)
+#undef KC
+#undef KCA
+#undef CA
+#undef CC
+  // one table: planes first, then vectors
+  for (int i = 0; i < vecs.nvec; ++i) { planes.src[planes.nplane + i] = vecs.src[i]; planes.dst[planes.nplane + i] = vecs.dst[i]; }
+  planes.nvec = vecs.nvec;
+  h->timed_valid = false;
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  launch_accumulate(v, planes, weight, reset, h->s_main);
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+  return finish(h, false);
+}
+
 // ================================================================================= synth ==
 
 extern "C" int obgc_synth_fill(obgc_handle* h, const obgc_synth_args* a) {

@@ -29,7 +29,41 @@ __global__ __launch_bounds__(kBlock) void apply_tendencies_kernel(GridView g, do
   x[ix] = v;
 }
 
+// Running means of many arrays in one launch: blockIdx.y picks the (source, destination) pair from a table that
+// travels as a kernel argument (scalar loads), so ~160 small streaming updates cost one launch, not 160.
+__global__ __launch_bounds__(kBlock) void accumulate_planes_kernel(GridView g, AccumTable t, double w, int reset) {
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= ncell) return;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  const long long ix = g.at(k, c);
+  const double* __restrict__ src = t.src[blockIdx.y];
+  double* __restrict__ dst = t.dst[blockIdx.y];
+  const double v = w * src[ix];
+  dst[ix] = reset ? v : dst[ix] + v;
+}
+
+__global__ __launch_bounds__(kBlock) void accumulate_vectors_kernel(int ncol, AccumTable t, double w, int reset) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= ncol) return;
+  const int e = t.nplane + blockIdx.y;
+  const double v = w * t.src[e][c];
+  t.dst[e][c] = reset ? v : t.dst[e][c] + v;
+}
+
 }  // namespace
+
+void launch_accumulate(const GridView& g, const AccumTable& t, double w, int reset, hipStream_t s) {
+  const long long ncell = (long long)g.nlev * g.ncol;
+  if (t.nplane > 0 && ncell > 0)
+    hipLaunchKernelGGL(accumulate_planes_kernel, dim3((unsigned)((ncell + kBlock - 1) / kBlock), (unsigned)t.nplane), dim3(kBlock), 0, s,
+                       g, t, w, reset);
+  if (t.nvec > 0 && g.ncol > 0)
+    hipLaunchKernelGGL(accumulate_vectors_kernel, dim3((unsigned)((g.ncol + kBlock - 1) / kBlock), (unsigned)t.nvec), dim3(kBlock), 0, s,
+                       g.ncol, t, w, reset);
+}
 
 void launch_apply_tendencies(const GridView& g, int ntracer, double* x, const double* t, const double* nf, const double* dz,
                              const int* kmax, double dt, int clamp, hipStream_t s) {

@@ -115,6 +115,14 @@ void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s)
 void launch_dms_surface(const DmsSurfKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
 void launch_macros(const MacrosKernelArgs& a, const obgc_macros_params& p, hipStream_t s);
 void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s);
+// (source, destination) pairs of obgc_bgc_diag_accumulate: first `nplane` (k,column) planes, then `nvec` (column) vectors
+struct AccumTable {
+  enum { kMax = 176 };
+  const double* src[kMax];
+  double* dst[kMax];
+  int nplane, nvec;
+};
+void launch_accumulate(const GridView& g, const AccumTable& t, double w, int reset, hipStream_t s);
 void launch_apply_tendencies(const GridView& g, int ntracer, double* x, const double* t, const double* nf, const double* dz,
                              const int* kmax, double dt, int clamp, hipStream_t s);
 // LDS-tiled transposes between the reference's KFAST order and the native COLFAST order

@@ -221,6 +221,18 @@ class Engine:
         a.dt, a.clamp_nonneg = float(dt), 1 if clamp_nonneg else 0
         self._check(self.lib.obgc_apply_tendencies(self.h, C.byref(a)), "obgc_apply_tendencies")
 
+    def bgc_diag_accumulate(self, nlev, ncol, layout, inst, mean, weight, reset=False, ld=0, plane=0, ldc=0):
+        """mean[X] = (0 if reset else mean[X]) + weight*inst[X] for every diagnostic present in both dicts (device tensors)."""
+        names = L.BGC_DIAG_KC + L.BGC_DIAG_KCA + L.BGC_DIAG_CA + L.BGC_DIAG_C
+        any_arr = next(v for v in inst.values() if v is not None)
+        ms = self._memspace(any_arr)
+        g = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        di, dm = L.BgcDiag(), L.BgcDiag()
+        self._fill(di, names, inst, ms)
+        self._fill(dm, names, mean, ms)
+        self._check(self.lib.obgc_bgc_diag_accumulate(self.h, C.byref(g), C.byref(di), C.byref(dm), float(weight), 1 if reset else 0),
+                    "obgc_bgc_diag_accumulate")
+
     def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, **dev_arrays):
         """Fill device tensors (native COLFAST layout) with the synthetic workload."""
         a = L.SynthArgs()
