@@ -24,6 +24,8 @@
  *    so a non-zero status always means an engine problem (no GPU, bad argument,
  *    out of device memory), never a numerical one.  There is NO CPU fallback.
  *  - indices inside parameter structs are 1-based, like the reference's *_ind.
+ *  - a call with grid.ncol == 0 is a no-op that returns OBGC_OK (the reference's column loop does not
+ *    execute); its array pointers are not examined.
  *  - arrays are fp64; integers are 32-bit (BGC_r8 / BGC_i4, BGC_parms.F90:21-24).
  *  - the caller owns every array; the engine owns only scratch inside the handle and
  *    keeps no pointer after a call returns.  State carried between calls lives in the

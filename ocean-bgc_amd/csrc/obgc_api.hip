@@ -459,6 +459,7 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
 extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_args* a) {
   if (!h || !a) return OBGC_ERR_INVALID;
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->tracers || !a->temp || !a->salt || !a->zmid || !a->dz || !a->zbot || !a->lat || !a->kmax || !a->fesedflux ||
       !a->dust_flux_in || !a->sw_flux || !a->tend || !a->ph_prev || !a->ph_prev_alt)
     return fail(h, OBGC_ERR_INVALID, "obgc_bgc_source_sink: null array");
@@ -627,6 +628,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
 extern "C" int obgc_bgc_surface_fluxes(obgc_handle* h, const obgc_bgc_surface_fluxes_args* a) {
   if (!h || !a) return OBGC_ERR_INVALID;
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->tracers || !a->surfacePressure || !a->windSpeedSquared10m || !a->atmCO2 || !a->atmCO2_ALT_CO2 ||
       !a->surfaceDepth || !a->SST || !a->SSS || !a->iceFraction || !a->surface_pH || !a->surface_pH_alt_co2 ||
       !a->depositionFlux || !a->riverFlux || !a->gasFlux || !a->seaIceFlux || !a->netFlux)
@@ -690,6 +692,7 @@ extern "C" int obgc_bgc_surface_fluxes(obgc_handle* h, const obgc_bgc_surface_fl
 extern "C" int obgc_dms_source_sink(obgc_handle* h, const obgc_dms_source_sink_args* a) {
   if (!h || !a) return OBGC_ERR_INVALID;
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->tracers || !a->dz || !a->kmax || !a->SST || !a->sw_flux || !a->tend)
     return fail(h, OBGC_ERR_INVALID, "obgc_dms_source_sink: null array");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -739,6 +742,7 @@ extern "C" int obgc_dms_source_sink(obgc_handle* h, const obgc_dms_source_sink_a
 extern "C" int obgc_dms_surface_fluxes(obgc_handle* h, const obgc_dms_surface_fluxes_args* a) {
   if (!h || !a) return OBGC_ERR_INVALID;
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->lcalc_DMS_gas_flux) return OBGC_OK;   // DMS_mod.F90:846
   if (!a->tracers || !a->surfacePressure || !a->windSpeedSquared10m || !a->SST || !a->iceFraction || !a->netFlux)
     return fail(h, OBGC_ERR_INVALID, "obgc_dms_surface_fluxes: null array");
@@ -783,6 +787,7 @@ extern "C" int obgc_dms_surface_fluxes(obgc_handle* h, const obgc_dms_surface_fl
 extern "C" int obgc_macros_source_sink(obgc_handle* h, const obgc_macros_source_sink_args* a) {
   if (!h || !a) return OBGC_ERR_INVALID;
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->tracers || !a->kmax || !a->tend) return fail(h, OBGC_ERR_INVALID, "obgc_macros_source_sink: null array");
   HIP_TRY(h, hipSetDevice(h->device));
   const GridView v = make_view(a->grid);
@@ -831,6 +836,7 @@ extern "C" int obgc_macros_source_sink(obgc_handle* h, const obgc_macros_source_
 extern "C" int obgc_apply_tendencies(obgc_handle* h, const obgc_apply_tendencies_args* a) {
   if (!h || !a) return OBGC_ERR_INVALID;
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (a->grid.memspace != OBGC_MEM_DEVICE)
     return fail(h, OBGC_ERR_UNSUPPORTED, "obgc_apply_tendencies: tracers must be resident on the device (OBGC_MEM_DEVICE)");
   if (a->ntracer < 0 || !a->tracers || !a->tend || !a->kmax || (a->net_flux && !a->dz))

@@ -1,0 +1,105 @@
+"""Edge cases through the C ABI on the GPU: empty and tiny batches, columns that are all land, kmax beyond nlev,
+one-level columns, and the error paths (a status plus a message, never a crash and never a CPU fallback)."""
+import numpy as np
+import pytest
+
+import parity as P
+from conftest import has_gpu
+
+PATHS = ("device_colfast", "device_kfast", "host")
+
+
+@pytest.fixture(scope="module")
+def engines(pkg):
+    if not has_gpu():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False (no CPU fallback exists)")
+    from ocean_bgc_amd.modules import ColumnEngine
+    return {p: ColumnEngine(0, path=p) for p in PATHS}
+
+
+def _args(syn):
+    return (syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+            syn["sw"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PATHS)
+def test_empty_batch_is_a_no_op(engines, synth, path):
+    E = engines[path]
+    nz = 60
+    tr = np.zeros((30, 0, nz))
+    z = np.zeros((0, nz))
+    out = E.BGC_SourceSink(tr, z, z, z, z, z, np.zeros(0), np.zeros(0, dtype=np.int32), z, np.zeros(0), np.zeros(0), z, z)
+    assert out["tend"].shape == (30, 0, nz)
+    assert E.MACROS_SourceSink(np.zeros((8, 0, nz)), np.zeros(0, dtype=np.int32))["tend"].shape == (8, 0, nz)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("nc,nz", [(1, 60), (3, 1), (65, 2), (127, 7)])
+def test_tiny_and_odd_shapes(engines, oracle, synth, path, nc, nz):
+    E = engines[path]
+    syn = synth.generate(nc, nz, col0=77)
+    syn["kmax"] = np.minimum(syn["kmax"], nz).astype(np.int32)
+    tr = synth.bgc_tracer_array(syn)
+    z = np.zeros((nc, nz))
+    rep = P.compare_bgc(E.BGC_SourceSink(tr, *_args(syn), z, z), oracle.bgc_source_sink(tr, *_args(syn), z, z), dz=syn["dz"])
+    assert rep.ok(), "\n".join(rep.fail[:8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PATHS)
+def test_all_land_and_kmax_beyond_nlev(engines, oracle, synth, path):
+    E = engines[path]
+    nc, nz = 130, 60
+    syn = synth.generate(nc, nz, col0=5)
+    tr = synth.bgc_tracer_array(syn)
+    z = np.zeros((nc, nz))
+    land = dict(syn)
+    land["kmax"] = np.zeros(nc, dtype=np.int32)
+    got = E.BGC_SourceSink(tr, *_args(land), z + 7.5, z + 7.5, diag_init=-7.0)
+    assert (got["tend"] == 0.0).all()                      # zero fill of the reference (BGC_mod.F90:570)
+    assert (got["ph_prev"] == 7.5).all()                   # PH_PREV_* untouched where nothing is solved
+    assert (got["kc"]["POC_ACCUM"] == -7.0).all() and (got["kc"]["CO3"] == 0.0).all()
+    deep = dict(syn)
+    deep["kmax"] = (syn["kmax"] + 1000).astype(np.int32)   # clamped to nlev by the engine like the loop bound would
+    full = dict(syn)
+    full["kmax"] = np.full(nc, nz, dtype=np.int32)
+    a = E.BGC_SourceSink(tr, *_args(deep), z, z)
+    b = E.BGC_SourceSink(tr, *_args(full), z, z)
+    assert np.array_equal(a["tend"], b["tend"]) and np.array_equal(a["ph_prev"], b["ph_prev"])
+    rep = P.compare_bgc(b, oracle.bgc_source_sink(tr, *_args(full), z, z))
+    assert rep.ok(), "\n".join(rep.fail[:8])
+
+
+@pytest.mark.gpu
+def test_error_paths_return_a_status_and_a_message(pkg, synth):
+    import ctypes as C
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine, ObgcError, make_grid
+    E = Engine(0)
+    lib = E.lib
+    # NULL arguments / bad grid
+    assert lib.obgc_bgc_source_sink(E.h, None) == -1
+    a = L.MacrosSourceSinkArgs()
+    a.grid = make_grid(0, 10, L.OBGC_LAYOUT_COLFAST, L.OBGC_MEM_HOST, 0, 0, 0)       # nlev = 0
+    assert lib.obgc_macros_source_sink(E.h, C.byref(a)) == -1
+    assert b"obgc_grid" in lib.obgc_last_error(E.h)
+    a.grid = make_grid(10, 10, L.OBGC_LAYOUT_COLFAST, L.OBGC_MEM_HOST, 0, 0, 0)       # valid grid, NULL arrays
+    assert lib.obgc_macros_source_sink(E.h, C.byref(a)) == -1
+    assert b"null" in lib.obgc_last_error(E.h)
+    # nutrient restoring is dead code in the reference: rejected, not silently ignored
+    p = L.BgcParams()
+    lib.obgc_bgc_params_init(C.byref(p), None, 273.15)
+    p.lrest_no3 = 1
+    assert lib.obgc_set_bgc_params(E.h, C.byref(p)) == -5
+    # resident-tracer entry points refuse host memory instead of staging it
+    x = np.zeros((30, 4, 3))
+    with pytest.raises(ObgcError, match="UNSUPPORTED"):
+        E.apply_tendencies(3, 4, L.OBGC_LAYOUT_KFAST, x, x, np.ones(4, dtype=np.int32), 1.0)
+    # the handle survives all of it
+    syn = synth.generate(8, 5, col0=1)
+    from ocean_bgc_amd.modules import ColumnEngine
+    CE = ColumnEngine(0, path="host")
+    out = CE.MACROS_SourceSink(synth.macros_tracer_array(syn), syn["kmax"])
+    assert np.isfinite(out["tend"]).all()
