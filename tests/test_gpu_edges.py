@@ -103,3 +103,32 @@ def test_error_paths_return_a_status_and_a_message(pkg, synth):
     CE = ColumnEngine(0, path="host")
     out = CE.MACROS_SourceSink(synth.macros_tracer_array(syn), syn["kmax"])
     assert np.isfinite(out["tend"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["device_colfast", "host"])
+def test_poisoned_columns_stay_in_their_lane(engines, synth, path):
+    """The reference cannot fail: bad input (NaN tracers, a zero-thickness level -> 0/0) silently
+    poisons its own column.  The engine must do the same: return, not hang in the Newton loops, and leave every
+    other column's bits exactly as they are without the bad neighbours."""
+    E = engines[path]
+    nc, nz = 200, 60
+    syn = synth.generate(nc, nz, col0=11)
+    tr = synth.bgc_tracer_array(syn)
+    z = np.zeros((nc, nz))
+    clean = E.BGC_SourceSink(tr, *_args(syn), z, z)
+    bad = dict(syn)
+    bad["dz"] = syn["dz"].copy()
+    bad["dz"][17, 5] = 0.0                       # 0/0 in the light and particle terms of column 17
+    trb = tr.copy()
+    trb[6, 64, :] = np.nan                       # DIC of column 64: the carbonate solve sees NaN
+    trb[1, 65, 3] = np.inf                       # NO3 of one cell of column 65
+    out = E.BGC_SourceSink(trb, *_args(bad), z, z)
+    good = np.ones(nc, dtype=bool)
+    good[[17, 64, 65]] = False
+    assert np.array_equal(out["tend"][:, good], clean["tend"][:, good])
+    assert np.array_equal(out["ph_prev"][good], clean["ph_prev"][good])
+    for grp in ("kc", "kca"):
+        for nm in clean[grp]:
+            assert np.array_equal(out[grp][nm][..., good, :], clean[grp][nm][..., good, :]), nm
+    assert not np.isfinite(out["tend"][:, 17]).all()
