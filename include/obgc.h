@@ -324,6 +324,25 @@ int obgc_apply_tendencies(obgc_handle *h, const obgc_apply_tendencies_args *a);
 int obgc_bgc_diag_accumulate(obgc_handle *h, const obgc_grid *grid, const obgc_bgc_diag *inst,
                              const obgc_bgc_diag *mean, double weight, int reset);
 
+/* ------------------------------- parameter files and restart state
+ * Host-only helpers (no GPU needed).  The reference has no file format: its parameters are module variables.
+ * Text format: sections [bgc], [autotroph N], [dms], [macros]; `name = value` with the reference's names; reals
+ * are written as C99 hex floats (exact round trip), read as decimal or hex.  Reading only overrides the listed
+ * keys, so initialise the structs first (obgc_*_params_init); unknown keys are errors (message in `err`).
+ * Any of the three struct pointers may be NULL (section skipped on write, parsed but ignored on read).
+ * After editing kSiO3 / *_calcifier / slots call obgc_bgc_params_derive. */
+int obgc_params_write_text(const char *path, const obgc_bgc_params *bgc, const obgc_dms_params *dms,
+                           const obgc_macros_params *macros);
+int obgc_params_read_text(const char *path, obgc_bgc_params *bgc, obgc_dms_params *dms, obgc_macros_params *macros,
+                          char *err, int errlen);
+/* Restart file of the only state carried between calls: PH_PREV_3D, PH_PREV_ALT_CO2_3D (nlev,ncol) and
+ * surface_pH, surface_pH_alt_co2 (ncol), HOST arrays in the reference's order; 64-byte header "OBGCRST1". */
+int obgc_restart_write(const char *path, int nlev, int ncol, const double *ph_prev, const double *ph_prev_alt,
+                       const double *surface_pH, const double *surface_pH_alt);
+int obgc_restart_read_header(const char *path, int *nlev, int *ncol);
+int obgc_restart_read(const char *path, int nlev, int ncol, double *ph_prev, double *ph_prev_alt, double *surface_pH,
+                      double *surface_pH_alt);
+
 /* ----------------------------------------------- workload utilities (bench/tests)
  * Deterministic synthetic columns, generated on the device in the
  * engine's native COLFAST layout for global columns [col0, col0+ncol).  Bit-identical

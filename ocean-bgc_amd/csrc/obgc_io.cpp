@@ -1,0 +1,231 @@
+// Parameter text files and the restart file of the only persistent state.
+// Host-only code (no HIP): lets stand-alone drivers, benchmarks and regression suites run the engine with an
+// explicit, versioned parameter set and carry PH_PREV_* / surface_pH* across runs.  The reference has no file
+// format of its own (its parameters are Fortran module variables set by *_parms_init and edited by the host).
+//
+// Parameter file: UTF-8 text, '#' comments, sections [bgc], [autotroph N] (N = 1..4), [dms], [macros]; one
+// `name = value` per line; names are the reference's (include/obgc_fields.h).  Reals are written as C99 hex floats
+// (exact round trip) and read with strtod (decimal or hex).  A file only overrides the keys it lists: the structs
+// must hold defaults (obgc_*_params_init) before reading.  Unknown keys or sections are errors, not warnings.
+//
+// Restart file: little-endian binary, 64-byte header
+//   char magic[8] = "OBGCRST1"; int32 nlev, ncol; int32 reserved[12];
+// followed by four fp64 arrays in the reference's order: PH_PREV_3D(nlev,ncol), PH_PREV_ALT_CO2_3D(nlev,ncol),
+// surface_pH(ncol), surface_pH_alt_co2(ncol).
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "obgc.h"
+
+namespace {
+
+void set_err(char* err, int errlen, const std::string& msg) {
+  if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", msg.c_str());
+}
+
+std::string trim(const std::string& s) {
+  size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+  return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+
+bool parse_real(const std::string& v, double& out) {
+  errno = 0;
+  char* end = nullptr;
+  out = std::strtod(v.c_str(), &end);
+  return end != v.c_str() && *end == '\0' && errno == 0;
+}
+
+bool parse_int(const std::string& v, int& out) {
+  errno = 0;
+  char* end = nullptr;
+  long x = std::strtol(v.c_str(), &end, 10);
+  out = (int)x;
+  return end != v.c_str() && *end == '\0' && errno == 0;
+}
+
+bool set_bgc(obgc_bgc_params* p, const std::string& k, const std::string& v) {
+#define X(n) if (k == #n) return parse_real(v, p->n);
+  OBGC_BGC_PARMS(X)
+#undef X
+  if (k == "T0_Kelvin_BGC") return parse_real(v, p->T0_Kelvin_BGC);
+  for (int i = 0; i < 4; ++i) {
+    if (k == "parm_scalelen_z(" + std::to_string(i + 1) + ")") return parse_real(v, p->parm_scalelen_z[i]);
+    if (k == "parm_scalelen_vals(" + std::to_string(i + 1) + ")") return parse_real(v, p->parm_scalelen_vals[i]);
+  }
+  return false;
+}
+
+bool set_autotroph(obgc_autotroph* a, const std::string& k, const std::string& v) {
+#define X(n) if (k == #n) return parse_int(v, a->n);
+  OBGC_AUTOTROPH_INTS(X)
+#undef X
+#define X(n) if (k == #n) return parse_real(v, a->n);
+  OBGC_AUTOTROPH_REALS(X)
+#undef X
+  return false;
+}
+
+bool set_dms(obgc_dms_params* p, const std::string& k, const std::string& v) {
+#define X(n) if (k == #n) return parse_real(v, p->n);
+  OBGC_DMS_PARMS(X)
+#undef X
+  return false;
+}
+
+bool set_macros(obgc_macros_params* p, const std::string& k, const std::string& v) {
+#define X(n) if (k == #n) return parse_real(v, p->n);
+  OBGC_MACROS_PARMS(X)
+#undef X
+  return false;
+}
+
+struct RestartHeader {
+  char magic[8];
+  int32_t nlev, ncol;
+  int32_t reserved[12];
+};
+static_assert(sizeof(RestartHeader) == 64, "restart header is 64 bytes");
+const char kMagic[8] = {'O', 'B', 'G', 'C', 'R', 'S', 'T', '1'};
+
+}  // namespace
+
+extern "C" int obgc_params_write_text(const char* path, const obgc_bgc_params* bgc, const obgc_dms_params* dms,
+                                      const obgc_macros_params* macros) {
+  if (!path) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return OBGC_ERR_INVALID;
+  std::fprintf(f, "# obgc parameters v1 -- names as in the reference's *_parms modules; reals as C99 hex floats\n");
+  if (bgc) {
+    std::fprintf(f, "[bgc]\n");
+#define X(n) std::fprintf(f, "%s = %a\n", #n, bgc->n);
+    OBGC_BGC_PARMS(X)
+#undef X
+    std::fprintf(f, "T0_Kelvin_BGC = %a\n", bgc->T0_Kelvin_BGC);
+    for (int i = 0; i < 4; ++i) std::fprintf(f, "parm_scalelen_z(%d) = %a\n", i + 1, bgc->parm_scalelen_z[i]);
+    for (int i = 0; i < 4; ++i) std::fprintf(f, "parm_scalelen_vals(%d) = %a\n", i + 1, bgc->parm_scalelen_vals[i]);
+    for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) {
+      std::fprintf(f, "[autotroph %d]\n", a + 1);
+#define X(n) std::fprintf(f, "%s = %d\n", #n, bgc->autotrophs[a].n);
+      OBGC_AUTOTROPH_INTS(X)
+#undef X
+#define X(n) std::fprintf(f, "%s = %a\n", #n, bgc->autotrophs[a].n);
+      OBGC_AUTOTROPH_REALS(X)
+#undef X
+    }
+  }
+  if (dms) {
+    std::fprintf(f, "[dms]\n");
+#define X(n) std::fprintf(f, "%s = %a\n", #n, dms->n);
+    OBGC_DMS_PARMS(X)
+#undef X
+  }
+  if (macros) {
+    std::fprintf(f, "[macros]\n");
+#define X(n) std::fprintf(f, "%s = %a\n", #n, macros->n);
+    OBGC_MACROS_PARMS(X)
+#undef X
+  }
+  return std::fclose(f) == 0 ? OBGC_OK : OBGC_ERR_INVALID;
+}
+
+extern "C" int obgc_params_read_text(const char* path, obgc_bgc_params* bgc, obgc_dms_params* dms, obgc_macros_params* macros,
+                                     char* err, int errlen) {
+  if (!path) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "r");
+  if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return OBGC_ERR_INVALID; }
+  enum { NONE, BGC, AUTO, DMS, MACROS } sec = NONE;
+  int autotroph = 0, lineno = 0;
+  char buf[512];
+  int rc = OBGC_OK;
+  while (rc == OBGC_OK && std::fgets(buf, sizeof buf, f)) {
+    ++lineno;
+    std::string line(buf);
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.erase(hash);
+    line = trim(line);
+    if (line.empty()) continue;
+    auto bad = [&](const std::string& why) {
+      set_err(err, errlen, std::string(path) + ":" + std::to_string(lineno) + ": " + why);
+      rc = OBGC_ERR_INVALID;
+    };
+    if (line.front() == '[') {
+      if (line.back() != ']') { bad("unterminated section header"); break; }
+      const std::string name = trim(line.substr(1, line.size() - 2));
+      if (name == "bgc") sec = BGC;
+      else if (name == "dms") sec = DMS;
+      else if (name == "macros") sec = MACROS;
+      else if (name.rfind("autotroph", 0) == 0 && parse_int(trim(name.substr(9)), autotroph) && autotroph >= 1 &&
+               autotroph <= OBGC_AUTOTROPH_CNT) sec = AUTO;
+      else bad("unknown section [" + name + "]");
+      continue;
+    }
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) { bad("expected name = value"); break; }
+    const std::string k = trim(line.substr(0, eq)), v = trim(line.substr(eq + 1));
+    bool ok = false;
+    switch (sec) {
+      case BGC: ok = !bgc || set_bgc(bgc, k, v); break;
+      case AUTO: ok = !bgc || set_autotroph(&bgc->autotrophs[autotroph - 1], k, v); break;
+      case DMS: ok = !dms || set_dms(dms, k, v); break;
+      case MACROS: ok = !macros || set_macros(macros, k, v); break;
+      case NONE: bad("key before any section"); continue;
+    }
+    if (!ok) bad("unknown key or malformed value: " + k + " = " + v);
+  }
+  std::fclose(f);
+  return rc;
+}
+
+extern "C" int obgc_restart_write(const char* path, int nlev, int ncol, const double* ph_prev, const double* ph_prev_alt,
+                                  const double* surface_pH, const double* surface_pH_alt) {
+  if (!path || nlev < 1 || ncol < 0 || (ncol > 0 && (!ph_prev || !ph_prev_alt || !surface_pH || !surface_pH_alt)))
+    return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return OBGC_ERR_INVALID;
+  RestartHeader h;
+  std::memset(&h, 0, sizeof h);
+  std::memcpy(h.magic, kMagic, 8);
+  h.nlev = nlev;
+  h.ncol = ncol;
+  const size_t n3 = (size_t)nlev * (size_t)ncol, n2 = (size_t)ncol;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+  ok = ok && std::fwrite(ph_prev, sizeof(double), n3, f) == n3 && std::fwrite(ph_prev_alt, sizeof(double), n3, f) == n3;
+  ok = ok && std::fwrite(surface_pH, sizeof(double), n2, f) == n2 && std::fwrite(surface_pH_alt, sizeof(double), n2, f) == n2;
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? OBGC_OK : OBGC_ERR_INVALID;
+}
+
+extern "C" int obgc_restart_read_header(const char* path, int* nlev, int* ncol) {
+  if (!path || !nlev || !ncol) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return OBGC_ERR_INVALID;
+  RestartHeader h;
+  const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, kMagic, 8) == 0 && h.nlev >= 1 && h.ncol >= 0;
+  std::fclose(f);
+  if (!ok) return OBGC_ERR_INVALID;
+  *nlev = h.nlev;
+  *ncol = h.ncol;
+  return OBGC_OK;
+}
+
+extern "C" int obgc_restart_read(const char* path, int nlev, int ncol, double* ph_prev, double* ph_prev_alt, double* surface_pH,
+                                 double* surface_pH_alt) {
+  int fl = 0, fc = 0;
+  int rc = obgc_restart_read_header(path, &fl, &fc);
+  if (rc != OBGC_OK) return rc;
+  if (fl != nlev || fc != ncol || (ncol > 0 && (!ph_prev || !ph_prev_alt || !surface_pH || !surface_pH_alt))) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return OBGC_ERR_INVALID;
+  const size_t n3 = (size_t)nlev * (size_t)ncol, n2 = (size_t)ncol;
+  bool ok = std::fseek(f, (long)sizeof(RestartHeader), SEEK_SET) == 0;
+  ok = ok && std::fread(ph_prev, sizeof(double), n3, f) == n3 && std::fread(ph_prev_alt, sizeof(double), n3, f) == n3;
+  ok = ok && std::fread(surface_pH, sizeof(double), n2, f) == n2 && std::fread(surface_pH_alt, sizeof(double), n2, f) == n2;
+  // the file must end here
+  ok = ok && std::fgetc(f) == EOF;
+  std::fclose(f);
+  return ok ? OBGC_OK : OBGC_ERR_INVALID;
+}
