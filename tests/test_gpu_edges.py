@@ -132,3 +132,43 @@ def test_poisoned_columns_stay_in_their_lane(engines, synth, path):
         for nm in clean[grp]:
             assert np.array_equal(out[grp][nm][..., good, :], clean[grp][nm][..., good, :]), nm
     assert not np.isfinite(out["tend"][:, 17]).all()
+
+
+@pytest.mark.gpu
+def test_async_handle_orders_its_own_work(pkg, synth):
+    """OBGC_ASYNC: device-memory calls return after enqueue.  Back-to-back calls on one handle (source/sink into
+    buffer set 1, source/sink of other tracers into set 2, explicit update consuming set 1) must give the bits of
+    the synchronous handle once obgc_sync has returned -- scratch reuse and the side streams are stream-ordered."""
+    import torch
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    nc, nz = 4000, 60
+    syn = synth.generate(nc, nz, col0=9)
+    dev = torch.device("cuda:0")
+
+    def up(x):        # reference order [.., c, k] -> native [.., k, c]
+        return torch.from_numpy(np.ascontiguousarray(x)).to(dev).transpose(-1, -2).contiguous()
+
+    def run(flags):
+        E = Engine(0, flags=flags)
+        tr1 = up(synth.bgc_tracer_array(syn))
+        tr2 = up(synth.bgc_tracer_array(syn) * 1.01)
+        kc = {k: up(syn[k]) for k in ("temp", "salt", "zmid", "dz", "zbot", "fesed")}
+        cc = {k: torch.from_numpy(np.ascontiguousarray(syn[k])).to(dev) for k in ("lat", "dust", "sw")}
+        kmax = torch.from_numpy(syn["kmax"].astype(np.int32)).to(dev)
+        outs = []
+        for _ in range(2):
+            outs.append(dict(tend=torch.zeros((30, nz, nc), dtype=torch.float64, device=dev),
+                             php=torch.zeros((nz, nc), dtype=torch.float64, device=dev),
+                             pha=torch.zeros((nz, nc), dtype=torch.float64, device=dev)))
+        torch.cuda.synchronize()
+        for tr, o in ((tr1, outs[0]), (tr2, outs[1])):
+            E.bgc_source_sink(nz, nc, L.OBGC_LAYOUT_COLFAST, tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"], cc["lat"],
+                              kmax, kc["fesed"], cc["dust"], cc["sw"], o["tend"], o["php"], o["pha"], None, True)
+        E.apply_tendencies(nz, nc, L.OBGC_LAYOUT_COLFAST, tr1, outs[0]["tend"], kmax, 600.0)
+        E.sync()
+        return [tr1.cpu().numpy()] + [o[k].cpu().numpy() for o in outs for k in ("tend", "php", "pha")]
+
+    a, b = run(0), run(L.OBGC_ASYNC if hasattr(L, "OBGC_ASYNC") else 1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
