@@ -320,7 +320,17 @@ def main():
                 traffic = tab["runs"]["%s_%s" % (args.config, dk)][key]["total"]
         except Exception:
             traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # fp64 VALU issue utilisation of the kernels (SQ_ACTIVE_INST_VALU PMC pass of this kernel revision,
+        # profiles/valu.json): SURVEY.md 8d asks for it next to the HBM fraction
+        valu = None
+        try:
+            vt = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+            rev = open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip()
+            if vt.get("kernel_rev") == rev and not args.columns:
+                valu = {k: round(v["valu_busy"], 3) for k, v in vt["runs"]["%s_%s" % (args.config, dk)].items()}
+        except Exception:
+            valu = None
+        roofline = {"bound": "hbm", "kernel": dom, "fp64_valu_busy": valu, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": active_cells * b_dom,
                     "algorithmic_bytes_per_cell": b_dom, "active_cells_per_launch": active_cells,
