@@ -14,6 +14,13 @@
 
 using namespace obgc;
 
+// (k,column) diagnostics written by bgc_sweep_kernel (the others come from the cell and carbonate kernels)
+#define OBGC_SWEEP_DIAG_KC(X) \
+  X(POC_FLUX_IN) X(POC_PROD) X(POC_REMIN) X(CaCO3_FLUX_IN) X(CaCO3_PROD) X(CaCO3_REMIN) X(SiO2_FLUX_IN) X(SiO2_PROD) \
+  X(SiO2_REMIN) X(dust_FLUX_IN) X(dust_REMIN) X(P_iron_FLUX_IN) X(P_iron_PROD) X(P_iron_REMIN) X(calcToSed) X(bsiToSed) \
+  X(pocToSed) X(SedDenitrif) X(OtherRemin) X(ponToSed) X(popToSed) X(dustToSed) X(pfeToSed) X(DENITRIF) X(O2_CONSUMPTION) \
+  X(Fe_scavenge) X(Fe_scavenge_rate)
+
 struct obgc_handle {
   int device = 0;
   unsigned flags = 0;
@@ -26,6 +33,7 @@ struct obgc_handle {
   int sweep_lanes = 0;    // experiment knob OBGC_SWEEP_LANES: 16 / 32 / 64 active lanes per wavefront in the sweep, 0 = auto
   int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
   int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides
+  int kfast_hybrid = 1;   // OBGC_KFAST_HYBRID=0: transpose every plane (the first implementation) instead of only the column kernels' planes
   int sched = 1;   // OBGC_SCHED: 0 carbonate from the start, 1 (default) carbonate released after the cell kernel, 2 carbonate inside the cell kernel
   obgc_bgc_params bgc;
   obgc_dms_params dms;
@@ -296,6 +304,7 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   for (auto e : evs)
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_KFAST_HYBRID")) h->kfast_hybrid = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
   if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_TILE")) { const int t = std::atoi(e); if (t >= 64) h->kfast_tile = t; }
@@ -452,6 +461,120 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   return OBGC_OK;
 }
 
+// Reference layout (level-fastest) on the device, hybrid scheme.  The cell-parallel kernels (attenuation, cell,
+// carbonate) are layout-agnostic -- their lanes run along whatever axis is contiguous -- so they work on the caller's
+// arrays directly.  Only the column kernels (PAR scan, sweep, column integrals, saturation horizons) need
+// column-fastest rows; the ~50 planes they read and the ~40 they write are transposed through LDS tiles, one
+// table-driven launch per batch, instead of all 200 planes of the call.  Per column tile of `tile` columns.
+//   K : the caller's view (kfast) with engine scratch carved in the same index space
+//   W : a dense column-fastest workspace view of one tile (own scratch), filled/drained here
+int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, bool want_zsat, int tile) {
+  const GridView& v = K.g;
+  const obgc_bgc_params& P = h->bgc;
+  const long long wl = W.g.sk;
+  const int staged[10] = {P.ind[1], P.ind[3], P.ind[4], P.ind[2], P.ind[0], P.ind[14], P.ind[13], P.ind[6], P.ind[8], P.ind[5]};
+  for (int c0 = 0; c0 < v.ncol; c0 += tile) {
+    const int nc = (v.ncol - c0 < tile) ? (v.ncol - c0) : tile;
+    const long long off = (long long)c0 * v.sc;
+    // ---- the caller's view of this tile
+    BgcKernelArgs Kt = K;
+    Kt.g.ncol = nc;
+    Kt.tracers += off; Kt.temp += off; Kt.salt += off; Kt.zmid += off; Kt.dz += off; Kt.zbot += off; Kt.fesed += off;
+    Kt.tend += off; Kt.ph_prev += off; Kt.ph_prev_alt += off; Kt.scratch += off;
+    Kt.lat += c0; Kt.kmax += c0; Kt.dust += c0; Kt.sw += c0;
+    if (Kt.co3_out) { Kt.co3_out += off; Kt.sat_calc_out += off; Kt.sat_arag_out += off; }
+    if (Kt.z_photoC) { Kt.z_photoC += off; Kt.z_photoC_NO3 += off; Kt.z_CaCO3_form += off; Kt.z_bSi_form += off; }
+#define X(n) if (Kt.diag.n) Kt.diag.n += off;
+    OBGC_BGC_DIAG_KC(X)
+    OBGC_BGC_DIAG_KCA(X)
+#undef X
+#define X(n) if (Kt.diag.n) Kt.diag.n += c0;
+    OBGC_BGC_DIAG_CA(X)
+    OBGC_BGC_DIAG_C(X)
+#undef X
+    // ---- the workspace view of this tile: per-column arrays are the caller's
+    BgcKernelArgs Wt = W;
+    Wt.g.ncol = nc;
+    Wt.lat = Kt.lat; Wt.kmax = Kt.kmax; Wt.dust = Kt.dust; Wt.sw = Kt.sw;
+#define X(n) Wt.diag.n = Kt.diag.n;
+    OBGC_BGC_DIAG_CA(X)
+    OBGC_BGC_DIAG_C(X)
+#undef X
+    auto kscr = [&](int slot) { return Kt.scratch + (long long)slot * Kt.splane; };
+    auto wscr = [&](int slot) { return Wt.scratch + (long long)slot * Wt.splane; };
+    auto ktr = [&](int slot1) { return Kt.tracers + (long long)(slot1 - 1) * v.plane; };
+    auto wtr = [&](int slot1) { return const_cast<double*>(Wt.tracers) + (long long)(slot1 - 1) * Wt.g.plane; };
+
+    HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+    // inputs of the column kernels that do not depend on this call's kernels
+    PlaneTable tin; tin.n = 0;
+    tin.add(Kt.dz, const_cast<double*>(Wt.dz)); tin.add(Kt.zbot, const_cast<double*>(Wt.zbot));
+    tin.add(Kt.fesed, const_cast<double*>(Wt.fesed)); tin.add(Kt.temp, const_cast<double*>(Wt.temp));
+    tin.add(Kt.zmid, const_cast<double*>(Wt.zmid));
+    tin.add(ktr(P.ind[1]), wtr(P.ind[1])); tin.add(ktr(P.ind[4]), wtr(P.ind[4])); tin.add(ktr(P.ind[5]), wtr(P.ind[5]));
+    launch_transpose_table_k2c(tin, v.nlev, nc, v.sc, wl, h->s_main);
+    if (c0 == 0) HIP_TRY(h, hipEventRecord(h->ev_t0, h->s_main));
+    // light: attenuation per cell (caller layout) -> scan per column (workspace) -> PAR entering each cell
+    launch_bgc_att(Kt, P, h->s_main);
+    PlaneTable t1; t1.n = 0; t1.add(kscr(S_ATT), wscr(S_ATT));
+    launch_transpose_table_k2c(t1, v.nlev, nc, v.sc, wl, h->s_main);
+    launch_bgc_parscan(Wt, h->s_main);
+    PlaneTable t2; t2.n = 0; t2.add(wscr(S_PARIN), kscr(S_PARIN));
+    launch_transpose_table_c2k(t2, v.nlev, nc, wl, v.sc, nullptr, h->s_main);
+    HIP_TRY(h, hipEventRecord(h->ev_k0, h->s_main));
+    launch_bgc_cell(Kt, P, h->s_main, 0);
+    HIP_TRY(h, hipEventRecord(h->ev_k1, h->s_main));
+    h->cell_valid = true;
+    // carbonate on the caller's layout beside the sweep; its three profiles feed the saturation-horizon scan
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
+    HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
+    launch_bgc_carbonate(Kt, P, h->s_aux);
+    HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+    if (want_zsat) {
+      PlaneTable tz; tz.n = 0;
+      tz.add(Kt.co3_out, Wt.co3_out); tz.add(Kt.sat_calc_out, Wt.sat_calc_out); tz.add(Kt.sat_arag_out, Wt.sat_arag_out);
+      launch_transpose_table_k2c(tz, v.nlev, nc, v.sc, wl, h->s_aux);
+      launch_bgc_zsat(Wt, h->s_aux);
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
+    // hand-off of the cell kernel: production terms, parked tendencies (+ DIC_ALT_CO2's plane, whose zero fill must
+    // survive), with diagnostics the local integrands and the four production profiles
+    PlaneTable th; th.n = 0;
+    th.add(kscr(S_PRODPOC), wscr(S_PRODPOC)); th.add(kscr(S_PRODCA), wscr(S_PRODCA)); th.add(kscr(S_PRODSI), wscr(S_PRODSI));
+    th.add(kscr(S_PFELOC), wscr(S_PFELOC));
+    for (int i = 0; i < 10; ++i) th.add(Kt.tend + (long long)(staged[i] - 1) * v.plane, Wt.tend + (long long)(staged[i] - 1) * Wt.g.plane);
+    if (K.have_diag) {
+      for (int sl = S_OC0; sl < S_NDIAG; ++sl) th.add(kscr(sl), wscr(sl));
+      for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) {
+        th.add(Kt.z_photoC + a * v.plane, Wt.z_photoC + a * Wt.g.plane);
+        th.add(Kt.z_photoC_NO3 + a * v.plane, Wt.z_photoC_NO3 + a * Wt.g.plane);
+        th.add(Kt.z_CaCO3_form + a * v.plane, Wt.z_CaCO3_form + a * Wt.g.plane);
+        th.add(Kt.z_bSi_form + a * v.plane, Wt.z_bSi_form + a * Wt.g.plane);
+      }
+    }
+    launch_transpose_table_k2c(th, v.nlev, nc, v.sc, wl, h->s_main);
+    HIP_TRY(h, hipEventRecord(h->ev_t1, h->s_main));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux2, h->ev_t1, 0));
+    launch_bgc_zint(Wt, P, h->s_aux2);
+    HIP_TRY(h, hipEventRecord(h->ev_aux2_done, h->s_aux2));
+    launch_bgc_ecosys_sweep(Wt, P, h->s_main, h->sweep_lanes);
+    HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+    // results of the sweep: 11 tendencies + its level-dependent diagnostics, active cells only
+    PlaneTable to; to.n = 0;
+    for (int i = 0; i < 10; ++i) to.add(Wt.tend + (long long)(staged[i] - 1) * Wt.g.plane, Kt.tend + (long long)(staged[i] - 1) * v.plane);
+    to.add(Wt.tend + (long long)(P.ind[7] - 1) * Wt.g.plane, Kt.tend + (long long)(P.ind[7] - 1) * v.plane);
+    if (K.have_diag) {
+#define X(n) if (Kt.diag.n) to.add(Wt.diag.n, Kt.diag.n);
+      OBGC_SWEEP_DIAG_KC(X)
+#undef X
+    }
+    launch_transpose_table_c2k(to, v.nlev, nc, wl, v.sc, Kt.kmax, h->s_main);
+    HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux2_done, 0));
+  }
+  return OBGC_OK;
+}
+
 }  // namespace
 
 // ======================================================================== BGC_SourceSink ==
@@ -510,6 +633,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   // time, so that every kernel runs on coalesced column-fastest rows (OBGC_KFAST_DIRECT=1 keeps the
   // generic-stride path for A/B measurements).
   const bool tiled = v.kfast && !h->kfast_direct;
+  const bool hybrid = tiled && h->kfast_hybrid;
   const int tile_cols = tiled ? (v.ncol < h->kfast_tile ? v.ncol : h->kfast_tile) : v.ncol;
   GridView kv = v;                       // the view the kernels see
   if (tiled) {
@@ -529,7 +653,13 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
     }
     work = align_up(tplane * (size_t)(30 + 6 + 2 + 30 + n_kc_out + 4 * n_kca_out));
   }
-  const size_t scratch = bgc_scratch_bytes(kv, a->diag, want_zsat, tiled);
+  obgc_bgc_diag wdiag0;                   // hybrid: the workspace owns every level-dependent plane it uses
+  std::memset(&wdiag0, 0, sizeof wdiag0);
+  size_t scratch = bgc_scratch_bytes(kv, a->diag, want_zsat, tiled);
+  if (hybrid) {
+    work = align_up(tplane * (size_t)(30 + 5 + 30 + 27));
+    scratch = bgc_scratch_bytes(v, a->diag, want_zsat, false) + bgc_scratch_bytes(kv, a->diag ? &wdiag0 : nullptr, want_zsat, true);
+  }
   int rc = arena_reserve(h, (st.host ? st.need : 0) + work + scratch);
   if (rc != OBGC_OK) return rc;
   rc = stage_in(h, st);
@@ -554,6 +684,34 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
     bgc_carve_scratch(h, K, want_zsat);
     rc = bgc_launch(h, K, want_zsat);
     if (rc != OBGC_OK) return rc;
+  } else if (hybrid) {
+    bgc_carve_scratch(h, K, want_zsat);               // scratch of the cell-parallel kernels, caller's index space
+    auto carve = [&](size_t bytes) -> double* {
+      double* p = (double*)(h->arena + h->arena_used);
+      h->arena_used += align_up(bytes);
+      return p;
+    };
+    double* w = carve(work);
+    auto take = [&](int nplanes) -> double* { double* p = w; w += (tplane / sizeof(double)) * nplanes; return p; };
+    BgcKernelArgs W = K;
+    W.g = kv;
+    W.tracers = take(30);
+    W.dz = take(1); W.zbot = take(1); W.fesed = take(1); W.temp = take(1); W.zmid = take(1);
+    W.salt = nullptr;
+    W.tend = take(30);
+    W.ph_prev = W.ph_prev_alt = nullptr;
+    W.co3_out = W.sat_calc_out = W.sat_arag_out = nullptr;
+    W.z_photoC = W.z_photoC_NO3 = W.z_CaCO3_form = W.z_bSi_form = nullptr;
+    std::memset(&W.diag, 0, sizeof W.diag);
+    bgc_carve_scratch(h, W, want_zsat);               // W.diag is empty here: profiles and CO3/sat planes come from the arena
+    if (a->diag) {
+#define X(n) if (dd.n) W.diag.n = take(1);
+      OBGC_SWEEP_DIAG_KC(X)
+#undef X
+    }
+    rc = bgc_launch_hybrid(h, K, W, want_zsat, tile_cols);
+    if (rc != OBGC_OK) return rc;
+    h->tr_valid = true;
   } else {
     // ---- native workspace (dense, column-fastest) ----
     auto carve = [&](size_t bytes) -> double* {

@@ -944,15 +944,21 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
 
 }  // namespace
 
-void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1,
-                             int fuse_carbonate) {
-  if (a.g.ncol <= 0) return;
-  const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
+void launch_bgc_att(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
   const long long ncell = (long long)a.g.nlev * a.g.ncol;
-  const unsigned gcell = (unsigned)((ncell + kBlockCell - 1) / kBlockCell);
+  if (ncell <= 0) return;
   hipLaunchKernelGGL(bgc_att_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, p);
-  hipLaunchKernelGGL(bgc_parscan_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a);
-  if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
+}
+
+void launch_bgc_parscan(const BgcKernelArgs& a, hipStream_t s) {
+  if (a.g.ncol <= 0) return;
+  hipLaunchKernelGGL(bgc_parscan_kernel, dim3((unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol)), dim3(kBlockCol), 0, s, a);
+}
+
+void launch_bgc_cell(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int fuse_carbonate) {
+  const long long ncell = (long long)a.g.nlev * a.g.ncol;
+  if (ncell <= 0) return;
+  const unsigned gcell = (unsigned)((ncell + kBlockCell - 1) / kBlockCell);
   if (fuse_carbonate) {
     if (a.have_diag) hipLaunchKernelGGL((bgc_cell_kernel<true, 1>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
     else hipLaunchKernelGGL((bgc_cell_kernel<false, 1>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
@@ -960,6 +966,15 @@ void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, h
     if (a.have_diag) hipLaunchKernelGGL((bgc_cell_kernel<true, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
     else hipLaunchKernelGGL((bgc_cell_kernel<false, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p);
   }
+}
+
+void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1,
+                             int fuse_carbonate) {
+  if (a.g.ncol <= 0) return;
+  launch_bgc_att(a, p, s);
+  launch_bgc_parscan(a, s);
+  if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
+  launch_bgc_cell(a, p, s, fuse_carbonate);
   if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
 }
 

@@ -132,6 +132,21 @@ void launch_transpose_k2c(const double* src, double* dst, int nlev, int ncol, lo
 void launch_transpose_c2k(const double* src, double* dst, int nlev, int ncol, long long src_ld,
                           long long src_plane, long long dst_ld, long long dst_plane, int nplanes, hipStream_t s);
 
+// table of unrelated planes moved by one transpose launch
+struct PlaneTable {
+  enum { kMax = 64 };
+  const double* src[kMax];
+  double* dst[kMax];
+  int n;
+  void add(const double* s, double* d) { src[n] = s; dst[n] = d; ++n; }
+};
+void launch_transpose_table_k2c(const PlaneTable& t, int nlev, int ncol, long long src_ld, long long dst_ld, hipStream_t s);
+void launch_transpose_table_c2k(const PlaneTable& t, int nlev, int ncol, long long src_ld, long long dst_ld, const int* kmax,
+                                hipStream_t s);
+void launch_bgc_att(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
+void launch_bgc_parscan(const BgcKernelArgs& a, hipStream_t s);
+void launch_bgc_cell(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int fuse_carbonate);
+
 // ---------------------------------------------------------------- small device helpers
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }

@@ -36,6 +36,41 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   }
 }
 
+// The same tile transposition for a TABLE of unrelated planes (one launch, blockIdx.z picks the pair).  With `kmax`
+// (level-fastest destination only: rows r = levels, q = columns) cells at or below the sea floor are not written,
+// so a destination that already holds the reference's zero fill keeps it.
+__global__ __launch_bounds__(256) void transpose_table_kernel(PlaneTable t, int R, int Q, long long src_ld, long long dst_ld,
+                                                              const int* __restrict__ kmax) {
+  __shared__ double tile[TILE][TILE + 1];
+  const int q0 = blockIdx.x * TILE, r0 = blockIdx.y * TILE;
+  const double* __restrict__ src = t.src[blockIdx.z];
+  double* __restrict__ dst = t.dst[blockIdx.z];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < TILE; i += 4) {
+    const int r = r0 + ty + i, q = q0 + tx;
+    if (r < R && q < Q) tile[ty + i][tx] = src[(long long)r * src_ld + q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TILE; i += 4) {
+    const int q = q0 + ty + i, r = r0 + tx;
+    if (r < R && q < Q && (!kmax || r < kmax[q])) dst[(long long)q * dst_ld + r] = tile[tx][ty + i];
+  }
+}
+
+void launch_table(const PlaneTable& t, int R, int Q, long long src_ld, long long dst_ld, const int* kmax, hipStream_t s) {
+  if (R <= 0 || Q <= 0 || t.n <= 0) return;
+  const int maxRows = 65535 * TILE;
+  for (int r0 = 0; r0 < R; r0 += maxRows) {
+    const int rr = (R - r0 < maxRows) ? (R - r0) : maxRows;
+    PlaneTable tt = t;
+    for (int i = 0; i < t.n; ++i) { tt.src[i] = t.src[i] + (long long)r0 * src_ld; tt.dst[i] = t.dst[i] + r0; }
+    dim3 grid((Q + TILE - 1) / TILE, (rr + TILE - 1) / TILE, t.n);
+    hipLaunchKernelGGL(transpose_table_kernel, grid, dim3(256), 0, s, tt, rr, Q, src_ld, dst_ld, kmax);
+  }
+}
+
 void launch(const double* src, double* dst, int R, int Q, long long src_ld, long long dst_ld, long long src_plane,
             long long dst_plane, int nplanes, hipStream_t s) {
   if (R <= 0 || Q <= 0 || nplanes <= 0) return;
@@ -59,6 +94,16 @@ void launch_transpose_k2c(const double* src, double* dst, int nlev, int ncol, lo
 void launch_transpose_c2k(const double* src, double* dst, int nlev, int ncol, long long src_ld, long long src_plane,
                           long long dst_ld, long long dst_plane, int nplanes, hipStream_t s) {
   launch(src, dst, nlev, ncol, src_ld, dst_ld, src_plane, dst_plane, nplanes, s);   // rows = levels, q = column
+}
+
+void launch_transpose_table_k2c(const PlaneTable& t, int nlev, int ncol, long long src_ld, long long dst_ld, hipStream_t s) {
+  launch_table(t, ncol, nlev, src_ld, dst_ld, nullptr, s);   // rows = columns, q = level
+}
+
+void launch_transpose_table_c2k(const PlaneTable& t, int nlev, int ncol, long long src_ld, long long dst_ld, const int* kmax,
+                                hipStream_t s) {
+  // rows = levels: one launch never needs the row split (nlev is small), so the mask indexes columns q directly
+  launch_table(t, nlev, ncol, src_ld, dst_ld, kmax, s);
 }
 
 }  // namespace obgc
