@@ -125,6 +125,14 @@ class ApplyTendenciesArgs(C.Structure):
                 ("kmax", _dptr), ("dt", C.c_double), ("clamp_nonneg", C.c_int)]
 
 
+class BlockStepArgs(C.Structure):
+    _fields_ = [(n, _dptr) for n in (
+        "ecosysTracers", "layerThickness", "zMid", "temperature", "salinity", "maxLevelCell", "latCell", "shortWaveHeatFlux",
+        "atmosphericPressure", "iceFraction", "windSpeedSquared10m", "atmosphericCO2", "atmosphericCO2_ALT_CO2", "dustFlux",
+        "ironSedimentFlux", "depositionFlux", "riverFlux", "seaIceFlux", "ecosysTracersTend", "ecosysSurfaceFlux")] + \
+        [("accumulate", C.c_int)]
+
+
 class SynthArgs(C.Structure):
     _fields_ = [("nlev", C.c_int), ("ncol", C.c_int), ("col0", C.c_longlong), ("ld", C.c_longlong),
                 ("plane", C.c_longlong), ("ldc", C.c_longlong), ("ind", C.POINTER(C.c_int)), ("tracers", _dptr),
@@ -166,6 +174,9 @@ PROTOTYPES = {
     "obgc_restart_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dptr, _dptr, _dptr, _dptr]),
     "obgc_restart_read_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "obgc_restart_read": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dptr, _dptr, _dptr, _dptr]),
+    "obgc_block_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "obgc_block_destroy": (C.c_int, [C.c_void_p]),
+    "obgc_block_step": (C.c_int, [C.c_void_p, C.POINTER(BlockStepArgs)]),
     "obgc_synth_fill": (C.c_int, [C.c_void_p, C.POINTER(SynthArgs)]),
 }
 

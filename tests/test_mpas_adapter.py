@@ -107,7 +107,8 @@ def test_adapter_sources_are_generated():
     spec = importlib.util.spec_from_file_location("gen_shim", os.path.join(FDIR, "gen_shim.py"))
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
-    for fn, lines in (("obgc_mpas_adapter.F90", g.mpas_adapter()), ("test_mpas_adapter.F90", g.mpas_test_program())):
+    for fn, lines in (("obgc_mpas_adapter.F90", g.mpas_adapter()), ("test_mpas_adapter.F90", g.mpas_test_program()),
+                      ("obgc_mpas_resident.F90", g.mpas_resident())):
         assert open(os.path.join(FDIR, fn)).read() == "\n".join(g.wrap(lines)) + "\n", fn
     src = open(os.path.join(FDIR, "obgc_mpas_adapter.F90")).read()
     # only the reference's public module API
@@ -149,6 +150,11 @@ def test_adapter_on_gpu_batched_equals_per_cell_and_matches_oracle(tmp_path, syn
         res[mode] = read_result(fout, nc, nz)
     for k in res[0]:            # one batched call == the historical one-call-per-cell loop, bit for bit
         assert np.array_equal(res[0][k], res[1][k]), k
+    # the device-resident twin (Fortran module obgc_mpas_resident over obgc_block_*): same tendencies and fluxes
+    fout = str(tmp_path / "out2.bin")
+    run(EXE_GPU, fin, fout, 2, nsteps)
+    res2 = read_result(fout, nc, nz)
+    assert np.array_equal(res2["tend"], res[0]["tend"]) and np.array_equal(res2["sflux"], res[0]["sflux"])
     want = expected(oracle, pk, m, nc, nz, nsteps)
     rep = P.Report()
     P.compare_tend(rep, "mpas.tend", res[0]["tend"].transpose(2, 0, 1), want["tend"].transpose(2, 0, 1))
@@ -157,3 +163,74 @@ def test_adapter_on_gpu_batched_equals_per_cell_and_matches_oracle(tmp_path, syn
     for k in ("php", "pha", "sph", "spha"):
         rep.note("ph", k, P.e_norm(res[0][k], want[k]), P.TOL_PH)
     assert rep.ok(), "\n".join(rep.fail[:10])
+
+
+def block_step(L, eng, blk, m, nc, nz, tend, accumulate):
+    import ctypes as C
+    a = L.BlockStepArgs()
+    keep = []
+
+    def put(name, arr, dtype=np.float64):
+        x = np.ascontiguousarray(arr, dtype=dtype)
+        keep.append(x)
+        setattr(a, name, x.ctypes.data_as(C.c_void_p))
+        return x
+
+    put("ecosysTracers", m["tracers"]); put("layerThickness", m["h"]); put("zMid", m["zmid"]); put("temperature", m["temp"])
+    put("salinity", m["salt"]); put("maxLevelCell", m["kmax"], np.int32); put("latCell", m["lat"])
+    put("shortWaveHeatFlux", m["sw"]); put("atmosphericPressure", m["patm"]); put("iceFraction", m["ice"])
+    put("windSpeedSquared10m", m["wind"]); put("atmosphericCO2", m["co2"]); put("atmosphericCO2_ALT_CO2", m["co2alt"])
+    put("dustFlux", m["dust"]); put("ironSedimentFlux", m["fesed"])
+    for k, nm in (("depo", "depositionFlux"), ("river", "riverFlux"), ("seaice", "seaIceFlux")):
+        put(nm, m[k].T)                                  # Fortran (nCells, nTracers)
+    sflux = np.zeros((nc, 30))
+    a.ecosysTracersTend = tend.ctypes.data_as(C.c_void_p)
+    a.ecosysSurfaceFlux = sflux.ctypes.data_as(C.c_void_p)
+    a.accumulate = 1 if accumulate else 0
+    rc = eng.lib.obgc_block_step(blk, C.byref(a))
+    assert rc == 0, (rc, eng.lib.obgc_last_error(eng.h))
+    return sflux
+
+
+@pytest.mark.gpu
+def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, oracle, pkg):
+    """The device-resident block (obgc_block_*): same bits as the Fortran adapter through the host path, parity bars
+    against the numpy + oracle restatement, and the accumulate switch."""
+    import ctypes as C
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    if not os.path.exists(EXE_GPU):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    nc, nz, nsteps = 640, 60, 2
+    m, pk = mpas_block(synth, nc, nz, col0=120000)
+    E = Engine(0)
+    blk = C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk)) == 0
+    tend = np.full((nc, nz, 30), 123.0)
+    for _ in range(nsteps):
+        tend[:] = 123.0                                   # overwritten, not accumulated
+        sflux = block_step(L, E, blk, m, nc, nz, tend, accumulate=False)
+    fin, fout = str(tmp_path / "blk.bin"), str(tmp_path / "out.bin")
+    write_block(fin, m, nc, nz)
+    run(EXE_GPU, fin, fout, 0, nsteps)
+    host = read_result(fout, nc, nz)
+    assert np.array_equal(tend, host["tend"]) and np.array_equal(sflux, host["sflux"])
+    want = expected(oracle, pk, m, nc, nz, nsteps)
+    rep = P.Report()
+    P.compare_tend(rep, "block.tend", tend.transpose(2, 0, 1), want["tend"].transpose(2, 0, 1))
+    rep.note("diag", "surface flux", P.e_norm(sflux, want["sflux"]), P.TOL_DIAG)
+    assert rep.ok(), "\n".join(rep.fail[:10])
+    # accumulate: a third step added on top of what the host already holds, active cells only
+    base = np.full((nc, nz, 30), 5.0)
+    acc = base.copy()
+    block_step(L, E, blk, m, nc, nz, acc, accumulate=True)
+    over = np.zeros((nc, nz, 30))
+    blk2 = C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk2)) == 0
+    for _ in range(nsteps + 1):
+        block_step(L, E, blk2, m, nc, nz, over, accumulate=False)
+    active = (np.arange(nz)[None, :] < m["kmax"][:, None])[:, :, None]
+    assert np.array_equal(acc, np.where(active, base + over, base))
+    assert E.lib.obgc_block_destroy(blk) == 0 and E.lib.obgc_block_destroy(blk2) == 0

@@ -1,0 +1,25 @@
+# one step of a device-resident mesh block (obgc_block_step) at cfg2 size, PCIe-inclusive:
+# only the model's arrays cross the link.  python tools/resident_block_bench.py
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from __graft_entry__ import load_pkg
+load_pkg()
+from ocean_bgc_amd import _lib as L, synth
+from ocean_bgc_amd.engine import Engine
+from test_mpas_adapter import mpas_block, block_step
+nc, nz = 100000, 60
+m, pk = mpas_block(synth, nc, nz, col0=0)
+E = Engine(0)
+blk = C.c_void_p()
+assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk)) == 0
+tend = np.zeros((nc, nz, 30))
+cells = int(m["kmax"].clip(0, nz).sum())
+for acc in (False, True):
+    ts = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        block_step(L, E, blk, m, nc, nz, tend, acc)
+        ts.append(time.perf_counter() - t0)
+    print("resident block step, accumulate=%s: best %.1f ms -> %.3e updates/s (PCIe-inclusive)" % (acc, 1e3 * min(ts[1:]), 30 * cells / min(ts[1:])), flush=True)
