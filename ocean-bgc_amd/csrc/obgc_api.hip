@@ -525,18 +525,6 @@ int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, b
     launch_bgc_cell(Kt, P, h->s_main, 0);
     HIP_TRY(h, hipEventRecord(h->ev_k1, h->s_main));
     h->cell_valid = true;
-    // carbonate on the caller's layout beside the sweep; its three profiles feed the saturation-horizon scan
-    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_k1, 0));
-    HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
-    launch_bgc_carbonate(Kt, P, h->s_aux);
-    HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
-    if (want_zsat) {
-      PlaneTable tz; tz.n = 0;
-      tz.add(Kt.co3_out, Wt.co3_out); tz.add(Kt.sat_calc_out, Wt.sat_calc_out); tz.add(Kt.sat_arag_out, Wt.sat_arag_out);
-      launch_transpose_table_k2c(tz, v.nlev, nc, v.sc, wl, h->s_aux);
-      launch_bgc_zsat(Wt, h->s_aux);
-    }
-    HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
     // hand-off of the cell kernel: production terms, parked tendencies (+ DIC_ALT_CO2's plane, whose zero fill must
     // survive), with diagnostics the local integrands and the four production profiles
     PlaneTable th; th.n = 0;
@@ -554,6 +542,19 @@ int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, b
     }
     launch_transpose_table_k2c(th, v.nlev, nc, v.sc, wl, h->s_main);
     HIP_TRY(h, hipEventRecord(h->ev_t1, h->s_main));
+    // carbonate on the caller's layout beside the sweep (not beside the bandwidth-bound transposes above, which its
+    // small workgroups would starve); its three profiles feed the saturation-horizon scan
+    HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_t1, 0));
+    HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
+    launch_bgc_carbonate(Kt, P, h->s_aux);
+    HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+    if (want_zsat) {
+      PlaneTable tz; tz.n = 0;
+      tz.add(Kt.co3_out, Wt.co3_out); tz.add(Kt.sat_calc_out, Wt.sat_calc_out); tz.add(Kt.sat_arag_out, Wt.sat_arag_out);
+      launch_transpose_table_k2c(tz, v.nlev, nc, v.sc, wl, h->s_aux);
+      launch_bgc_zsat(Wt, h->s_aux);
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
     HIP_TRY(h, hipStreamWaitEvent(h->s_aux2, h->ev_t1, 0));
     launch_bgc_zint(Wt, P, h->s_aux2);
     HIP_TRY(h, hipEventRecord(h->ev_aux2_done, h->s_aux2));

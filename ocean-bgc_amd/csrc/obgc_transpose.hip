@@ -42,10 +42,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 __global__ __launch_bounds__(256) void transpose_table_kernel(PlaneTable t, int R, int Q, long long src_ld, long long dst_ld,
                                                               const int* __restrict__ kmax) {
   __shared__ double tile[TILE][TILE + 1];
+  __shared__ int kmx[TILE];
   const int q0 = blockIdx.x * TILE, r0 = blockIdx.y * TILE;
   const double* __restrict__ src = t.src[blockIdx.z];
   double* __restrict__ dst = t.dst[blockIdx.z];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (threadIdx.x < TILE) kmx[threadIdx.x] = (kmax && q0 + (int)threadIdx.x < Q) ? kmax[q0 + threadIdx.x] : 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < TILE; i += 4) {
     const int r = r0 + ty + i, q = q0 + tx;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void transpose_table_kernel(PlaneTable t, int 
 #pragma unroll
   for (int i = 0; i < TILE; i += 4) {
     const int q = q0 + ty + i, r = r0 + tx;
-    if (r < R && q < Q && (!kmax || r < kmax[q])) dst[(long long)q * dst_ld + r] = tile[tx][ty + i];
+    if (r < R && q < Q && r < kmx[ty + i]) dst[(long long)q * dst_ld + r] = tile[tx][ty + i];
   }
 }
 
