@@ -874,9 +874,19 @@ extern "C" int obgc_dms_source_sink(obgc_handle* h, const obgc_dms_source_sink_a
     OBGC_DMS_DIAG_KC(X)
 #undef X
   }
-  int rc = stage_in(h, st);
+  // light hand-off: three planes in the caller's index space (+ two dense column-fastest ones for the reference layout)
+  const size_t dense = (size_t)v.nlev * v.ncol * sizeof(double);
+  const size_t scratch = 3 * align_up(kc1) + (v.kfast ? 2 * align_up(dense) : 0);
+  int rc = arena_reserve(h, (st.host ? st.need : 0) + scratch);
+  if (rc != OBGC_OK) return rc;
+  rc = stage_in(h, st);
   if (rc != OBGC_OK) return rc;
   for (auto& s : dslots) *s.first = st.dev<double>(s.second);
+  auto carve = [&](size_t bytes) -> double* {
+    double* p = (double*)(h->arena + h->arena_used);
+    h->arena_used += align_up(bytes);
+    return p;
+  };
   DmsKernelArgs K;
   std::memset(&K, 0, sizeof K);
   K.g = v;
@@ -884,6 +894,8 @@ extern "C" int obgc_dms_source_sink(obgc_handle* h, const obgc_dms_source_sink_a
   K.SST = st.dev<const double>(i_t); K.sw = st.dev<const double>(i_sw); K.tend = st.dev<double>(i_td);
   K.diag = dd;
   K.have_diag = a->diag ? 1 : 0;
+  K.s_att = carve(kc1); K.s_kpardz = carve(kc1); K.s_parin = carve(kc1);
+  if (v.kfast) { K.w_att = carve(dense); K.w_parin = carve(dense); }
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
   launch_dms(K, h->dms, h->s_main);
   HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));

@@ -14,20 +14,68 @@ namespace {
 constexpr int kBlockCol = 64;
 constexpr int kBlockCell = 256;
 
-template <bool DIAG>
-__global__ __launch_bounds__(kBlockCol) void dms_kernel(const DmsKernelArgs A, const obgc_dms_params P) {
+// DMS_SourceSink as three kernels, like the BGC light: only PAR is carried down the column (DMS_mod.F90:538-551),
+// everything else is cell-local, and cell-parallel kernels are indifferent to the layout (their lanes follow the
+// contiguous axis), which is what makes the reference layout as fast as the native one.
+//   dms_att_kernel   1 lane / cell     exp(-KPARdz), KPARdz
+//   dms_scan_kernel  1 lane / column   PAR entering each level (one multiply per level)
+//   dms_cell_kernel  1 lane / cell     the kinetics, 14 tendencies (12 of them zero), 27 diagnostics
+#define TRD(j, ix) dmax(0.0, A.tracers[(long long)(P.ind[j] - 1) * pl + (ix)])
+
+__global__ __launch_bounds__(kBlockCell) void dms_att_kernel(const DmsKernelArgs A, const obgc_dms_params P) {
   const GridView& g = A.g;
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
+  if (idx >= ncell) return;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  if (k >= A.kmax[c]) return;
+  const long long ix = g.at(k, c), pl = g.plane;
+  const double spChl = TRD(10, ix), diatChl = TRD(11, ix), diazChl = TRD(12, ix), phaeoChl = TRD(13, ix);
+  // light (538-551); the UV branch (531-536) produces nothing that is used
+  const double totalChl = spChl + diatChl + diazChl + phaeoChl;
+  const double work = dmax(totalChl, 0.02);
+  double KPARdz = (work < 0.13224) ? 0.000919 * pow(work, 0.3536) : 0.001131 * pow(work, 0.4562);
+  KPARdz = KPARdz * A.dz[ix];
+  A.s_kpardz[ix] = KPARdz;
+  A.s_att[ix] = exp(-KPARdz);
+}
+
+// `att` / `par_in` are column-fastest planes (dense, leading dimension ncol) when cf != 0, else in the view's own index space
+__global__ __launch_bounds__(kBlockCol) void dms_scan_kernel(GridView g, const int* __restrict__ kmaxv, const double* __restrict__ sw,
+                                                            const double* __restrict__ att, double* __restrict__ par_in, double f_qsw_par,
+                                                            int cf) {
   const int c = blockIdx.x * kBlockCol + threadIdx.x;
   if (c >= g.ncol) return;
-  const obgc_dms_diag& D = A.diag;
-  const long long pl = g.plane;
-  int kmax = A.kmax[c];
+  int kmax = kmaxv[c];
   if (kmax > g.nlev) kmax = g.nlev;
-#define TRD(j, ix) dmax(0.0, A.tracers[(long long)(P.ind[j] - 1) * pl + (ix)])
-#define ST(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
-  const double SST = A.SST[c];
-  double PAR_out = dmax(0.0, A.sw[c]) * P.f_qsw_par_DMS;   // 506-507
+  double PAR = dmax(0.0, sw[c]) * f_qsw_par;   // 506-507
+  for (int k = 0; k < kmax; ++k) {
+    const long long ix = cf ? (long long)k * g.ncol + c : g.at(k, c);
+    par_in[ix] = PAR;
+    PAR = PAR * att[ix];
+  }
+}
 
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockCell) void dms_cell_kernel(const DmsKernelArgs A, const obgc_dms_params P) {
+  const GridView& g = A.g;
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
+  if (idx >= ncell) return;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  const long long ix = g.at(k, c), pl = g.plane;
+  const obgc_dms_diag& D = A.diag;
+#define ST(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
+  if (k >= A.kmax[c]) {   // the reference zero-fills the tendencies of the whole array first
+#pragma unroll
+    for (int n = 0; n < OBGC_DMS_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
+    return;
+  }
+  const double SST = A.SST[c];
   // column-constant fuzzy-logic terms: they use the SURFACE temperature at every depth (504, 584-592, 637-640)
   double T_ind = (SST - P.T_lo) / (P.T_hi - P.T_lo);
   if (T_ind <= 0.0) T_ind = 0.0;
@@ -36,23 +84,12 @@ __global__ __launch_bounds__(kBlockCol) void dms_kernel(const DmsKernelArgs A, c
   double yield = (T_ind * (P.Max_yld - P.Min_yld)) + P.Min_yld;
   if (SST < P.T_cryo_hi && SST > P.T_cryo_lo) yield = 0.5;
   if (SST < -1.0) yield = 0.25;
-
-  for (int k = 0; k < kmax; ++k) {
-    const long long ix = g.at(k, c);
-    const double dz = A.dz[ix];
+  {
     const double DMS = TRD(0, ix), DMSP = TRD(1, ix), zooC = TRD(4, ix), spC = TRD(5, ix), spCaCO3 = TRD(6, ix),
-                 diatC = TRD(7, ix), diazC = TRD(8, ix), phaeoC = TRD(9, ix), spChl = TRD(10, ix), diatChl = TRD(11, ix),
-                 diazChl = TRD(12, ix), phaeoChl = TRD(13, ix);
-    const double k_S_p = P.k_S_p_base * (P.mort + (zooC / 0.3));          // 529: hard-wired 0.3, not zooC_avg
-    // light (538-551); the UV branch (531-536) produces nothing that is used
-    const double PAR_in = PAR_out;
-    const double totalChl = spChl + diatChl + diazChl + phaeoChl;
-    const double work = dmax(totalChl, 0.02);
-    double KPARdz = (work < 0.13224) ? 0.000919 * pow(work, 0.3536) : 0.001131 * pow(work, 0.4562);
-    KPARdz = KPARdz * dz;
-    const double att = exp(-KPARdz);
-    PAR_out = PAR_in * att;
+                 diatC = TRD(7, ix), diazC = TRD(8, ix), phaeoC = TRD(9, ix), spChl = TRD(10, ix);
+    const double PAR_in = A.s_parin[ix], att = A.s_att[ix], KPARdz = A.s_kpardz[ix];
     const double PAR_avg = PAR_in * (1.0 - att) / KPARdz;
+    const double k_S_p = P.k_S_p_base * (P.mort + (zooC / 0.3));          // 529: hard-wired 0.3, not zooC_avg
     const double j_dms = P.j_dms_perI * PAR_avg;
     // community partition (570-612)
     double Cocco_frac = spCaCO3 / (spC + 1.00e-8);
@@ -103,14 +140,10 @@ __global__ __launch_bounds__(kBlockCol) void dms_kernel(const DmsKernelArgs A, c
       ST(RSNzoo, Rs2n_zoo);
     }
   }
-  for (int k = (kmax > 0 ? kmax : 0); k < g.nlev; ++k) {
-    const long long ix = g.at(k, c);
-#pragma unroll
-    for (int n = 0; n < OBGC_DMS_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
-  }
-#undef TRD
 #undef ST
 }
+
+#undef TRD
 
 template <bool DIAG>
 __global__ __launch_bounds__(kBlockCell) void macros_kernel(const MacrosKernelArgs A, const obgc_macros_params P) {
@@ -151,10 +184,20 @@ __global__ __launch_bounds__(kBlockCell) void macros_kernel(const MacrosKernelAr
 }  // namespace
 
 void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s) {
-  if (a.g.ncol <= 0) return;
-  const unsigned grid = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
-  if (a.have_diag) hipLaunchKernelGGL(dms_kernel<true>, dim3(grid), dim3(kBlockCol), 0, s, a, p);
-  else hipLaunchKernelGGL(dms_kernel<false>, dim3(grid), dim3(kBlockCol), 0, s, a, p);
+  const long long ncell = (long long)a.g.nlev * a.g.ncol;
+  if (ncell <= 0) return;
+  const unsigned gcell = (unsigned)((ncell + kBlockCell - 1) / kBlockCell), gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
+  hipLaunchKernelGGL(dms_att_kernel, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  if (a.g.kfast && a.w_att) {   // reference layout: the scan runs on column-fastest twins of its two planes
+    const long long ld = a.g.sc;
+    launch_transpose_k2c(a.s_att, a.w_att, a.g.nlev, a.g.ncol, ld, 0, a.g.ncol, 0, 1, s);
+    hipLaunchKernelGGL(dms_scan_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a.g, a.kmax, a.sw, a.w_att, a.w_parin, p.f_qsw_par_DMS, 1);
+    launch_transpose_c2k(a.w_parin, a.s_parin, a.g.nlev, a.g.ncol, a.g.ncol, 0, ld, 0, 1, s);
+  } else {
+    hipLaunchKernelGGL(dms_scan_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a.g, a.kmax, a.sw, a.s_att, a.s_parin, p.f_qsw_par_DMS, 0);
+  }
+  if (a.have_diag) hipLaunchKernelGGL(dms_cell_kernel<true>, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
+  else hipLaunchKernelGGL(dms_cell_kernel<false>, dim3(gcell), dim3(kBlockCell), 0, s, a, p);
 }
 
 void launch_macros(const MacrosKernelArgs& a, const obgc_macros_params& p, hipStream_t s) {

@@ -84,6 +84,10 @@ struct DmsKernelArgs {
   double* tend;
   obgc_dms_diag diag;
   int have_diag;
+  // engine scratch in the caller's (k,column) index space: exp(-KPARdz), KPARdz, PAR entering the level
+  double *s_att, *s_kpardz, *s_parin;
+  // for the reference layout: column-fastest twins of s_att / s_parin (the PAR scan is the only column kernel)
+  double *w_att, *w_parin;
 };
 
 struct DmsSurfKernelArgs {
@@ -111,7 +115,7 @@ void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, h
 void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int lanes);
 void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_surface(const SurfKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
-void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
+void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s);   // att -> PAR scan -> cell kernel
 void launch_dms_surface(const DmsSurfKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
 void launch_macros(const MacrosKernelArgs& a, const obgc_macros_params& p, hipStream_t s);
 void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s);
