@@ -126,3 +126,33 @@ def test_cfg3_1M_x_60_tendencies_only(gpu):
     s = make_batch(torch, L, eng, nz, wn, w0, diag=False)
     run(L, eng, s)
     assert torch.equal(s["tend"], b["tend"][:, :, w0:w0 + wn]) and torch.equal(s["ph"], b["ph"][:, :, w0:w0 + wn])
+
+
+def test_reference_layout_equals_native_layout_at_scale(gpu, monkeypatch):
+    """The reference (level-fastest) layout on the device -- cell-parallel kernels on the caller's arrays, LDS transposes
+    for the column kernels' planes, several column tiles -- must leave exactly the bits of the native layout in every
+    output, including the zero fill below the sea floor and the untouched diagnostics."""
+    torch, L, eng = gpu
+    from ocean_bgc_amd.engine import Engine
+    nz, nc = 60, 100_000
+    b = make_batch(torch, L, eng, nz, nc, 777, diag=True)
+    run(L, eng, b)
+    monkeypatch.setenv("OBGC_KFAST_TILE", "32768")        # 4 tiles, the last one short
+    eng2 = Engine(0)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    t = lambda x: x.transpose(-1, -2).contiguous()         # [.., k, c] -> [.., c, k]
+    tend = torch.full((30, nc, nz), -7.0, **f64)
+    ph = torch.zeros((2, nc, nz), **f64)
+    diag = {}
+    for nm, v in b["diag"].items():
+        diag[nm] = torch.full(tuple(t(v).shape) if v.dim() >= 2 and v.shape[-2] == nz else tuple(v.shape), -7.0, **f64)
+    kc = {k: t(v) for k, v in b["kc"].items()}
+    torch.cuda.synchronize()
+    eng2.bgc_source_sink(nz, nc, L.OBGC_LAYOUT_KFAST, t(b["tr"]), kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"],
+                         b["cc"]["lat"], b["kmax"], kc["fesedflux"], b["cc"]["dust_flux_in"], b["cc"]["sw_flux"], tend, ph[0], ph[1],
+                         diag, True)
+    eng2.sync()
+    assert torch.equal(t(tend), b["tend"]) and torch.equal(t(ph), b["ph"])
+    for nm, v in b["diag"].items():
+        got = t(diag[nm]) if v.dim() >= 2 and v.shape[-2] == nz else diag[nm]
+        assert torch.equal(got, v), nm
