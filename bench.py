@@ -150,6 +150,9 @@ def main():
                     help="cold (headline): PH_PREV_* = 0 at every step, full [6, 9] bracket; warm (secondary timing of "
                          "SURVEY.md 8d): the previous step's pH is the bracket centre, as in a running model")
     ap.add_argument("--columns", type=int, default=0, help="override columns per GPU")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak (default, what the driver's scaling run uses): the config's columns on EVERY GPU; strong: "
+                         "the config's columns split over the GPUs (SURVEY.md 8d asks for both at cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -190,7 +193,13 @@ def main():
     ncol, nz, modules = CONFIGS[args.config]
     if args.columns:
         ncol = args.columns
-    col0, ncol = shard(rank, world, ncol)
+    if args.scaling == "strong":
+        total = ncol
+        ncol = (total + world - 1) // world          # the last rank takes what is left
+        col0 = rank * ncol
+        ncol = max(0, min(ncol, total - col0))
+    else:
+        col0, ncol = shard(rank, world, ncol)
     diag_on = args.diag == "full"
     eng = Engine(local_rank)
     f64 = dict(dtype=torch.float64, device=dev)
@@ -343,7 +352,7 @@ def main():
                             "bound by fp64 VALU issue (96 %); see DESIGN.md section 4"}
         out = {"metric": "column-level tracer updates/sec", "value": value, "unit": "updates/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s: %d columns x %d levels per GPU, %s, native column-fastest layout, "
                                       "diagnostics=%s, %s"
                                       % (args.config, ncol, nz, "+".join(modules), dk,

@@ -379,6 +379,15 @@ int obgc_restart_read_header(const char *path, int *nlev, int *ncol);
 int obgc_restart_read(const char *path, int nlev, int ncol, double *ph_prev, double *ph_prev_alt, double *surface_pH,
                       double *surface_pH_alt);
 
+/* ------------------------------------------------ column ranges for several devices
+ * No statement of the path reads another column (BGC_mod.F90:808-814 resets the only carried scalars), so N
+ * devices take N contiguous column ranges and exchange nothing.  Host-only helper: bounds[0..nparts] with
+ * bounds[0] = 0 <= ... <= bounds[nparts] = ncol; device p owns [bounds[p], bounds[p+1]).
+ *   balance = 0  equal column counts
+ *   balance = 1  equal numbers of ACTIVE cells, sum of max(kmax, 0): the cost of a range under ragged bathymetry
+ *                (kmax = number_of_active_levels, HOST pointer; may be NULL for balance = 0) */
+int obgc_partition_columns(const int *kmax, long long ncol, int nparts, int balance, long long *bounds);
+
 /* ----------------------------------------------- workload utilities (bench/tests)
  * Deterministic synthetic columns, generated on the device in the
  * engine's native COLFAST layout for global columns [col0, col0+ncol).  Bit-identical

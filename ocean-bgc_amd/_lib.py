@@ -172,6 +172,7 @@ PROTOTYPES = {
     "obgc_params_read_text": (C.c_int, [C.c_char_p, C.POINTER(BgcParams), C.POINTER(DmsParams), C.POINTER(MacrosParams),
                                         C.c_char_p, C.c_int]),
     "obgc_restart_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dptr, _dptr, _dptr, _dptr]),
+    "obgc_partition_columns": (C.c_int, [C.POINTER(C.c_int), C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "obgc_restart_read_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "obgc_restart_read": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dptr, _dptr, _dptr, _dptr]),
     "obgc_block_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

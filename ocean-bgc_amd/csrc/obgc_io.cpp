@@ -229,3 +229,28 @@ extern "C" int obgc_restart_read(const char* path, int nlev, int ncol, double* p
   std::fclose(f);
   return ok ? OBGC_OK : OBGC_ERR_INVALID;
 }
+
+// Static contiguous column ranges for `nparts` devices.  Columns are independent, so any cut is
+// legal; with ragged bathymetry the cost of a range is its number of ACTIVE cells, not of columns.
+//   balance = 0: equal column counts;  1: equal sums of max(kmax, 0) (prefix sum, cut at the first column whose
+//   prefix reaches p/nparts of the total).
+extern "C" int obgc_partition_columns(const int* kmax, long long ncol, int nparts, int balance, long long* bounds) {
+  if (!bounds || nparts < 1 || ncol < 0 || (balance != 0 && balance != 1) || (balance == 1 && ncol > 0 && !kmax))
+    return OBGC_ERR_INVALID;
+  long long total = 0;
+  if (balance == 1)
+    for (long long c = 0; c < ncol; ++c) total += kmax[c] > 0 ? kmax[c] : 0;
+  bounds[0] = 0;
+  bounds[nparts] = ncol;
+  if (balance == 0 || total == 0) {
+    for (int p = 1; p < nparts; ++p) bounds[p] = (long long)(((__int128)ncol * p) / nparts);
+    return OBGC_OK;
+  }
+  long long prefix = 0, c = 0;
+  for (int p = 1; p < nparts; ++p) {
+    const long long goal = (long long)(((__int128)total * p + nparts - 1) / nparts);   // ceil(total * p / nparts)
+    while (c < ncol && prefix < goal) { prefix += kmax[c] > 0 ? kmax[c] : 0; ++c; }
+    bounds[p] = c;
+  }
+  return OBGC_OK;
+}

@@ -30,6 +30,18 @@ def make_grid(nlev, ncol, layout, memspace, ld=0, plane=0, ldc=0):
     return g
 
 
+def partition_columns(kmax, nparts, balance="cells"):
+    """Contiguous column ranges for `nparts` devices (obgc_partition_columns; host-only, no GPU needed).
+    balance: "columns" (equal counts) or "cells" (equal sums of active levels).  -> list of nparts+1 bounds."""
+    kmax = np.ascontiguousarray(kmax, dtype=np.int32)
+    bounds = (C.c_longlong * (nparts + 1))()
+    rc = L.load().obgc_partition_columns(kmax.ctypes.data_as(C.POINTER(C.c_int)), kmax.size, nparts,
+                                         {"columns": 0, "cells": 1}[balance], bounds)
+    if rc != 0:
+        raise ObgcError("obgc_partition_columns: bad argument (rc=%d)" % rc)
+    return list(bounds)
+
+
 class Engine:
     """One obgc_handle = one GPU + its streams and scratch (one per host thread per GPU)."""
 

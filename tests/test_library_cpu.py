@@ -120,3 +120,30 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"(from|import)\s+oracle|oracle/|liboracle|libbgc_ref|obgc_oracle", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_partition_columns(L):
+    """obgc_partition_columns: contiguous ranges that tile the columns; with balance=cells no
+    range exceeds the mean number of active cells by more than one column's worth."""
+    from ocean_bgc_amd.engine import ObgcError, partition_columns
+    rng = np.random.default_rng(3)
+    # deep basin, a wide shelf, land: equal column counts would give the first device 20x the cells of the last
+    kmax = np.concatenate([np.full(1000, 60), rng.integers(1, 6, 5000), np.zeros(700, dtype=int), np.full(300, -1)]).astype(np.int32)
+    cells = np.maximum(kmax, 0)
+    for nparts in (1, 2, 3, 8, 64):
+        b = partition_columns(kmax, nparts, "columns")
+        assert b[0] == 0 and b[-1] == kmax.size and all(y >= x for x, y in zip(b, b[1:]))
+        assert max(y - x for x, y in zip(b, b[1:])) - min(y - x for x, y in zip(b, b[1:])) <= 1
+        b = partition_columns(kmax, nparts, "cells")
+        assert b[0] == 0 and b[-1] == kmax.size and all(y >= x for x, y in zip(b, b[1:]))
+        load = [int(cells[x:y].sum()) for x, y in zip(b, b[1:])]
+        assert sum(load) == int(cells.sum())
+        assert max(load) <= cells.sum() / nparts + cells.max()
+    # the cut is a pure function of the prefix sums: any split glued back gives every column exactly once
+    b = partition_columns(kmax, 5, "cells")
+    assert np.array_equal(np.concatenate([np.arange(x, y) for x, y in zip(b, b[1:])]), np.arange(kmax.size))
+    # all-land and empty inputs fall back to equal counts
+    assert partition_columns(np.zeros(10, dtype=np.int32), 4, "cells") == [0, 2, 5, 7, 10]
+    assert partition_columns(np.zeros(0, dtype=np.int32), 3, "cells") == [0, 0, 0, 0]
+    with pytest.raises(ObgcError):
+        partition_columns(kmax, 0, "cells")
