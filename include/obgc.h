@@ -359,6 +359,16 @@ int obgc_block_step(obgc_block *b, const obgc_block_step_args *a);
  * One launch for all selected members.  DEVICE pointers only; both layouts. */
 int obgc_bgc_diag_accumulate(obgc_handle *h, const obgc_grid *grid, const obgc_bgc_diag *inst,
                              const obgc_bgc_diag *mean, double weight, int reset);
+/* the same for the 27 DMS and the 6 MACROS diagnostics (DMS_parms.F90:125-154, MACROS_parms.F90:105-113) ... */
+int obgc_dms_diag_accumulate(obgc_handle *h, const obgc_grid *grid, const obgc_dms_diag *inst,
+                             const obgc_dms_diag *mean, double weight, int reset);
+int obgc_macros_diag_accumulate(obgc_handle *h, const obgc_grid *grid, const obgc_macros_diag *inst,
+                                const obgc_macros_diag *mean, double weight, int reset);
+/* ... and for any other resident arrays (flux diagnostics, tendencies, the host's own fields): HOST arrays of DEVICE
+ * pointers, `nplanes` arrays of (k,column) in grid's layout and `nvecs` arrays of (column); every pointer non-NULL. */
+int obgc_accumulate_arrays(obgc_handle *h, const obgc_grid *grid, int nplanes, const double *const *inst_planes,
+                           double *const *mean_planes, int nvecs, const double *const *inst_vecs,
+                           double *const *mean_vecs, double weight, int reset);
 
 /* ------------------------------- parameter files and restart state
  * Host-only helpers (no GPU needed).  The reference has no file format: its parameters are module variables.

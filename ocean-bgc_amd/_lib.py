@@ -168,6 +168,11 @@ PROTOTYPES = {
     "obgc_macros_source_sink": (C.c_int, [C.c_void_p, C.POINTER(MacrosSourceSinkArgs)]),
     "obgc_apply_tendencies": (C.c_int, [C.c_void_p, C.POINTER(ApplyTendenciesArgs)]),
     "obgc_bgc_diag_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.POINTER(BgcDiag), C.POINTER(BgcDiag), C.c_double, C.c_int]),
+    "obgc_dms_diag_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.POINTER(DmsDiag), C.POINTER(DmsDiag), C.c_double, C.c_int]),
+    "obgc_macros_diag_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.POINTER(MacrosDiag), C.POINTER(MacrosDiag), C.c_double,
+                                              C.c_int]),
+    "obgc_accumulate_arrays": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_double, C.c_int]),
     "obgc_params_write_text": (C.c_int, [C.c_char_p, C.POINTER(BgcParams), C.POINTER(DmsParams), C.POINTER(MacrosParams)]),
     "obgc_params_read_text": (C.c_int, [C.c_char_p, C.POINTER(BgcParams), C.POINTER(DmsParams), C.POINTER(MacrosParams),
                                         C.c_char_p, C.c_int]),

@@ -1028,34 +1028,36 @@ extern "C" int obgc_apply_tendencies(obgc_handle* h, const obgc_apply_tendencies
   return finish(h, false);
 }
 
-extern "C" int obgc_bgc_diag_accumulate(obgc_handle* h, const obgc_grid* grid, const obgc_bgc_diag* inst, const obgc_bgc_diag* mean,
-                                        double weight, int reset) {
-  if (!h || !grid || !inst || !mean) return OBGC_ERR_INVALID;
+namespace {
+
+// Shared tail of the *_accumulate entry points: `planes` are (k,column) arrays, `vecs` are (column) arrays, both lists of
+// (instantaneous, mean) device pointers.  Tables of AccumTable::kMax pointers per launch.
+struct AccumList {
+  std::vector<const double*> psrc, vsrc;
+  std::vector<double*> pdst, vdst;
+  void plane(const double* s, double* d) { psrc.push_back(s); pdst.push_back(d); }
+  void vec(const double* s, double* d) { vsrc.push_back(s); vdst.push_back(d); }
+};
+
+int accumulate_run(obgc_handle* h, const obgc_grid* grid, const AccumList& L, double weight, int reset, const char* who) {
   if (!grid_ok(*grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
   if (grid->memspace != OBGC_MEM_DEVICE)
-    return fail(h, OBGC_ERR_UNSUPPORTED, "obgc_bgc_diag_accumulate: diagnostics must be resident on the device (OBGC_MEM_DEVICE)");
+    return fail(h, OBGC_ERR_UNSUPPORTED, std::string(who) + ": diagnostics must be resident on the device (OBGC_MEM_DEVICE)");
   HIP_TRY(h, hipSetDevice(h->device));
   const GridView v = make_view(*grid);
   if (v.ncol == 0) return OBGC_OK;
-  AccumTable planes, vecs;
-  planes.nplane = planes.nvec = vecs.nplane = vecs.nvec = 0;
-  auto add_plane = [&](const double* s, double* d) { planes.src[planes.nplane] = s; planes.dst[planes.nplane] = d; ++planes.nplane; };
-  auto add_vec = [&](const double* s, double* d) { vecs.src[vecs.nvec] = s; vecs.dst[vecs.nvec] = d; ++vecs.nvec; };
-#define KC(n) if (inst->n && mean->n) add_plane(inst->n, mean->n);
-#define KCA(n) if (inst->n && mean->n) for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) add_plane(inst->n + a * v.plane, mean->n + a * v.plane);
-#define CA(n) if (inst->n && mean->n) for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) add_vec(inst->n + a * v.ldc, mean->n + a * v.ldc);
-#define CC(n) if (inst->n && mean->n) add_vec(inst->n, mean->n);
-  OBGC_BGC_DIAG_KC(KC) OBGC_BGC_DIAG_KCA(KCA) OBGC_BGC_DIAG_CA(CA) OBGC_BGC_DIAG_C(CC)
-#undef KC
-#undef KCA
-#undef CA
-#undef CC
-  // one table: planes first, then vectors
-  for (int i = 0; i < vecs.nvec; ++i) { planes.src[planes.nplane + i] = vecs.src[i]; planes.dst[planes.nplane + i] = vecs.dst[i]; }
-  planes.nvec = vecs.nvec;
   h->timed_valid = false;
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
-  launch_accumulate(v, planes, weight, reset, h->s_main);
+  size_t ip = 0, iv = 0;
+  while (ip < L.psrc.size() || iv < L.vsrc.size()) {   // planes first, then vectors, kMax pointers per table
+    AccumTable t;
+    t.nplane = t.nvec = 0;
+    while (ip < L.psrc.size() && t.nplane < AccumTable::kMax) { t.src[t.nplane] = L.psrc[ip]; t.dst[t.nplane] = L.pdst[ip]; ++t.nplane; ++ip; }
+    while (iv < L.vsrc.size() && t.nplane + t.nvec < AccumTable::kMax) {
+      t.src[t.nplane + t.nvec] = L.vsrc[iv]; t.dst[t.nplane + t.nvec] = L.vdst[iv]; ++t.nvec; ++iv;
+    }
+    launch_accumulate(v, t, weight, reset, h->s_main);
+  }
   HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
   HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_main));
   HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_main));
@@ -1064,6 +1066,61 @@ extern "C" int obgc_bgc_diag_accumulate(obgc_handle* h, const obgc_grid* grid, c
   HIP_TRY(h, hipGetLastError());
   h->timed_valid = true;
   return finish(h, false);
+}
+
+}  // namespace
+
+extern "C" int obgc_bgc_diag_accumulate(obgc_handle* h, const obgc_grid* grid, const obgc_bgc_diag* inst, const obgc_bgc_diag* mean,
+                                        double weight, int reset) {
+  if (!h || !grid || !inst || !mean) return OBGC_ERR_INVALID;
+  if (!grid_ok(*grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  const GridView v = make_view(*grid);
+  AccumList L;
+#define KC(n) if (inst->n && mean->n) L.plane(inst->n, mean->n);
+#define KCA(n) if (inst->n && mean->n) for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) L.plane(inst->n + a * v.plane, mean->n + a * v.plane);
+#define CA(n) if (inst->n && mean->n) for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) L.vec(inst->n + a * v.ldc, mean->n + a * v.ldc);
+#define CC(n) if (inst->n && mean->n) L.vec(inst->n, mean->n);
+  OBGC_BGC_DIAG_KC(KC) OBGC_BGC_DIAG_KCA(KCA) OBGC_BGC_DIAG_CA(CA) OBGC_BGC_DIAG_C(CC)
+#undef KCA
+#undef CA
+#undef CC
+  return accumulate_run(h, grid, L, weight, reset, "obgc_bgc_diag_accumulate");
+}
+
+extern "C" int obgc_dms_diag_accumulate(obgc_handle* h, const obgc_grid* grid, const obgc_dms_diag* inst, const obgc_dms_diag* mean,
+                                        double weight, int reset) {
+  if (!h || !grid || !inst || !mean) return OBGC_ERR_INVALID;
+  AccumList L;
+  OBGC_DMS_DIAG_KC(KC)
+  return accumulate_run(h, grid, L, weight, reset, "obgc_dms_diag_accumulate");
+}
+
+extern "C" int obgc_macros_diag_accumulate(obgc_handle* h, const obgc_grid* grid, const obgc_macros_diag* inst,
+                                           const obgc_macros_diag* mean, double weight, int reset) {
+  if (!h || !grid || !inst || !mean) return OBGC_ERR_INVALID;
+  AccumList L;
+  OBGC_MACROS_DIAG_KC(KC)
+#undef KC
+  return accumulate_run(h, grid, L, weight, reset, "obgc_macros_diag_accumulate");
+}
+
+// Any other resident arrays (flux diagnostics, tendencies, model fields): explicit pointer lists.
+extern "C" int obgc_accumulate_arrays(obgc_handle* h, const obgc_grid* grid, int nplanes, const double* const* inst_planes,
+                                      double* const* mean_planes, int nvecs, const double* const* inst_vecs, double* const* mean_vecs,
+                                      double weight, int reset) {
+  if (!h || !grid || nplanes < 0 || nvecs < 0 || (nplanes > 0 && (!inst_planes || !mean_planes)) ||
+      (nvecs > 0 && (!inst_vecs || !mean_vecs)))
+    return OBGC_ERR_INVALID;
+  AccumList L;
+  for (int i = 0; i < nplanes; ++i) {
+    if (!inst_planes[i] || !mean_planes[i]) return fail(h, OBGC_ERR_INVALID, "obgc_accumulate_arrays: null plane pointer");
+    L.plane(inst_planes[i], mean_planes[i]);
+  }
+  for (int i = 0; i < nvecs; ++i) {
+    if (!inst_vecs[i] || !mean_vecs[i]) return fail(h, OBGC_ERR_INVALID, "obgc_accumulate_arrays: null vector pointer");
+    L.vec(inst_vecs[i], mean_vecs[i]);
+  }
+  return accumulate_run(h, grid, L, weight, reset, "obgc_accumulate_arrays");
 }
 
 // ================================================================================= synth ==

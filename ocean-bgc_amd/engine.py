@@ -245,6 +245,38 @@ class Engine:
         self._check(self.lib.obgc_bgc_diag_accumulate(self.h, C.byref(g), C.byref(di), C.byref(dm), float(weight), 1 if reset else 0),
                     "obgc_bgc_diag_accumulate")
 
+    def _diag_accumulate(self, fn, struct, names, nlev, ncol, layout, inst, mean, weight, reset, ld, plane, ldc):
+        any_arr = next(v for v in inst.values() if v is not None)
+        ms = self._memspace(any_arr)
+        g = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
+        di, dm = struct(), struct()
+        self._fill(di, names, inst, ms)
+        self._fill(dm, names, mean, ms)
+        self._check(getattr(self.lib, fn)(self.h, C.byref(g), C.byref(di), C.byref(dm), float(weight), 1 if reset else 0), fn)
+
+    def dms_diag_accumulate(self, nlev, ncol, layout, inst, mean, weight, reset=False, ld=0, plane=0, ldc=0):
+        self._diag_accumulate("obgc_dms_diag_accumulate", L.DmsDiag, L.DMS_DIAG_KC, nlev, ncol, layout, inst, mean, weight, reset,
+                              ld, plane, ldc)
+
+    def macros_diag_accumulate(self, nlev, ncol, layout, inst, mean, weight, reset=False, ld=0, plane=0, ldc=0):
+        self._diag_accumulate("obgc_macros_diag_accumulate", L.MacrosDiag, L.MACROS_DIAG_KC, nlev, ncol, layout, inst, mean, weight,
+                              reset, ld, plane, ldc)
+
+    def accumulate_arrays(self, nlev, ncol, layout, planes=(), vecs=(), weight=1.0, reset=False, ld=0, plane=0, ldc=0):
+        """planes / vecs: sequences of (inst, mean) device tensors, (k,column) in `layout` resp. (column)."""
+        def table(pairs, j):
+            arr = (C.c_void_p * max(1, len(pairs)))()
+            for i, pr in enumerate(pairs):
+                addr, is_dev = _ptr(pr[j])
+                if not is_dev:
+                    raise ObgcError("accumulate_arrays needs device tensors")
+                arr[i] = addr
+            return arr
+        g = make_grid(nlev, ncol, layout, L.OBGC_MEM_DEVICE, ld, plane, ldc)
+        self._check(self.lib.obgc_accumulate_arrays(self.h, C.byref(g), len(planes), table(planes, 0), table(planes, 1), len(vecs),
+                                                    table(vecs, 0), table(vecs, 1), float(weight), 1 if reset else 0),
+                    "obgc_accumulate_arrays")
+
     def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, **dev_arrays):
         """Fill device tensors (native COLFAST layout) with the synthetic workload."""
         a = L.SynthArgs()

@@ -81,3 +81,46 @@ def test_means_of_real_steps(engines, pkg, synth):
     for nm, (s, k) in sh.items():
         assert np.array_equal(E._down(mean[nm], k), want[nm]), nm
     assert np.abs(want["photoC_TOT_zint"]).max() > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["device_colfast", "device_kfast"])
+def test_dms_macros_and_free_arrays_bit_exact(engines, pkg, path):
+    """obgc_dms_diag_accumulate, obgc_macros_diag_accumulate and obgc_accumulate_arrays (more pointers than one
+    launch table holds) against numpy."""
+    from ocean_bgc_amd import _lib as L
+    E = engines[path]
+    nc, nz = 333, 17
+    rng = np.random.default_rng(5)
+    for names, fn in ((L.DMS_DIAG_KC, E.eng.dms_diag_accumulate), (L.MACROS_DIAG_KC, E.eng.macros_diag_accumulate)):
+        skip = {names[1]}
+        mean_np = {nm: rng.standard_normal((nc, nz)) for nm in names}
+        mean_dev = {nm: (None if nm in skip else E._up(mean_np[nm], "kc")) for nm in names}
+        for w, reset in ((0.5, True), (0.25, False)):
+            inst_np = {nm: rng.standard_normal((nc, nz)) for nm in names}
+            fn(nz, nc, E._layout, {nm: E._up(inst_np[nm], "kc") for nm in names}, mean_dev, w, reset)
+            for nm in names:
+                mean_np[nm] = (0.0 if reset else mean_np[nm]) + w * inst_np[nm]
+        E.eng.sync()
+        for nm in names:
+            if nm not in skip:
+                assert np.array_equal(E._down(mean_dev[nm], "kc"), mean_np[nm]), (path, nm)
+    # free-form lists: 200 planes + 30 vectors = more than one table of 176 pointers
+    npl, nv = 200, 30
+    pi = [rng.standard_normal((nc, nz)) for _ in range(npl)]
+    pm = [rng.standard_normal((nc, nz)) for _ in range(npl)]
+    vi = [rng.standard_normal(nc) for _ in range(nv)]
+    vm = [rng.standard_normal(nc) for _ in range(nv)]
+    planes = [(E._up(a, "kc"), E._up(b, "kc")) for a, b in zip(pi, pm)]
+    vecs = [(E._up(a, "c"), E._up(b, "c")) for a, b in zip(vi, vm)]
+    E.eng.accumulate_arrays(nz, nc, E._layout, planes, vecs, weight=0.375, reset=False)
+    E.eng.accumulate_arrays(nz, nc, E._layout, planes[:3], (), weight=2.0, reset=True)
+    E.eng.sync()
+    for i in range(npl):
+        want = 2.0 * pi[i] if i < 3 else pm[i] + 0.375 * pi[i]
+        assert np.array_equal(E._down(planes[i][1], "kc"), want), (path, i)
+    for i in range(nv):
+        assert np.array_equal(E._down(vecs[i][1], "c"), vm[i] + 0.375 * vi[i]), (path, i)
+    # nothing to do / empty batch are no-ops
+    E.eng.accumulate_arrays(nz, nc, E._layout, (), (), weight=1.0)
+    E.eng.accumulate_arrays(nz, 0, E._layout, (), (), weight=1.0)
