@@ -36,7 +36,7 @@ def test_empty_batch_is_a_no_op(engines, synth, path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", PATHS)
-@pytest.mark.parametrize("nc,nz", [(1, 60), (3, 1), (65, 2), (127, 7)])
+@pytest.mark.parametrize("nc,nz", [(1, 60), (3, 1), (65, 2), (127, 7), (40, 200)])
 def test_tiny_and_odd_shapes(engines, oracle, synth, path, nc, nz):
     E = engines[path]
     syn = synth.generate(nc, nz, col0=77)
