@@ -6,8 +6,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "obgc_internal.h"
@@ -27,6 +30,9 @@ struct obgc_handle {
   hipStream_t s_main = nullptr;   // column-sweep kernels, copies, transposes
   hipStream_t s_aux = nullptr;    // cell-parallel carbonate kernel runs beside the sweep
   hipStream_t s_aux2 = nullptr;   // column integrals (diagnostics) run beside both
+  hipStream_t s_up = nullptr, s_down = nullptr;   // host-memory path: uploads / downloads of column chunks (created on first use)
+  int host_chunks = 4;    // OBGC_HOST_CHUNKS: column chunks of the pipelined host-memory path (0 or 1 = stage everything, then run)
+  size_t host_pipeline_min_bytes = (size_t)64 << 20;   // OBGC_HOST_PIPELINE_MIN_MB: smaller calls are staged in one piece
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
              ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_aux2_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool timed_valid = false, tr_valid = false, cell_valid = false;
@@ -86,6 +92,7 @@ struct Stage {
   void* host;
   size_t bytes;
   bool in, out;
+  int nplanes;   // > 0: a (k,column[,n]) array of that many planes, copied per column chunk by the pipelined host path
 };
 
 struct Stager {
@@ -97,10 +104,11 @@ struct Stager {
   // pass 1: register; returns an index
   int add(const void* p, size_t bytes, bool in, bool out) {
     if (!p) return -1;
-    items.push_back(Stage{nullptr, const_cast<void*>(p), bytes, in, out});
+    items.push_back(Stage{nullptr, const_cast<void*>(p), bytes, in, out, 0});
     need += align_up(bytes);
     return (int)items.size() - 1;
   }
+  int add_kc(const void* p, const GridView& v, int nplanes, bool in, bool out);
   template <class T>
   T* dev(int i) const { return i < 0 ? nullptr : (T*)items[(size_t)i].dev; }
 };
@@ -155,7 +163,14 @@ size_t span_c(const GridView& v, int nplanes) {
   return (size_t)((long long)(nplanes - 1) * v.ldc + v.ncol) * sizeof(double);
 }
 
-int stage_in(obgc_handle* h, Stager& st) {
+int Stager::add_kc(const void* p, const GridView& v, int nplanes, bool in, bool out) {
+  const int i = add(p, span_kc(v, nplanes), in, out);
+  if (i >= 0) items[(size_t)i].nplanes = nplanes;
+  return i;
+}
+
+// `chunked`: the (k,column) arrays travel per column chunk (host_pipeline below); only the small arrays move here
+int stage_in(obgc_handle* h, Stager& st, bool chunked = false) {
   if (!st.host) {
     for (auto& it : st.items) it.dev = it.host;
     return OBGC_OK;
@@ -166,18 +181,29 @@ int stage_in(obgc_handle* h, Stager& st) {
   for (auto& it : st.items) {
     it.dev = h->arena + off;
     off += align_up(it.bytes);
-    if (it.in) HIP_TRY(h, hipMemcpyAsync(it.dev, it.host, it.bytes, hipMemcpyHostToDevice, h->s_main));
+    if (it.in && !(chunked && it.nplanes > 0))
+      HIP_TRY(h, hipMemcpyAsync(it.dev, it.host, it.bytes, hipMemcpyHostToDevice, h->s_main));
   }
   h->arena_used = off;
   return OBGC_OK;
 }
 
-int stage_out(obgc_handle* h, Stager& st) {
+int stage_out(obgc_handle* h, Stager& st, bool chunked = false) {
   if (!st.host) return OBGC_OK;
   for (auto& it : st.items)
-    if (it.out) HIP_TRY(h, hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, h->s_main));
+    if (it.out && !(chunked && it.nplanes > 0))
+      HIP_TRY(h, hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, h->s_main));
   HIP_TRY(h, hipStreamSynchronize(h->s_main));
   return OBGC_OK;
+}
+
+// Byte range of columns [c0, c1) of plane n of a staged reference-layout array (contiguous: the column stride is the
+// leading dimension).  The last range ends with the array, which may stop short of a full leading dimension.
+inline void chunk_range(const Stage& it, const GridView& v, int n, int c0, int c1, size_t& begin, size_t& len) {
+  begin = (size_t)((long long)n * v.plane + (long long)c0 * v.sc) * sizeof(double);
+  size_t end = (size_t)((long long)n * v.plane + (long long)c1 * v.sc) * sizeof(double);
+  if (end > it.bytes) end = it.bytes;
+  len = end > begin ? end - begin : 0;
 }
 
 int finish(obgc_handle* h, bool force_sync) {
@@ -307,6 +333,8 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   if (const char* e = std::getenv("OBGC_KFAST_HYBRID")) h->kfast_hybrid = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
   if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_HOST_CHUNKS")) h->host_chunks = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_HOST_PIPELINE_MIN_MB")) h->host_pipeline_min_bytes = (size_t)std::atoll(e) << 20;
   if (const char* e = std::getenv("OBGC_KFAST_TILE")) { const int t = std::atoi(e); if (t >= 64) h->kfast_tile = t; }
   obgc_bgc_params_init(&h->bgc, nullptr, 273.15);
   obgc_dms_params_init(&h->dms, nullptr);
@@ -328,6 +356,8 @@ extern "C" int obgc_destroy(obgc_handle* h) {
   (void)hipStreamDestroy(h->s_main);
   (void)hipStreamDestroy(h->s_aux);
   if (h->s_aux2) (void)hipStreamDestroy(h->s_aux2);
+  if (h->s_up) (void)hipStreamDestroy(h->s_up);
+  if (h->s_down) (void)hipStreamDestroy(h->s_down);
   delete h;
   return OBGC_OK;
 }
@@ -468,13 +498,15 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
 // table-driven launch per batch, instead of all 200 planes of the call.  Per column tile of `tile` columns.
 //   K : the caller's view (kfast) with engine scratch carved in the same index space
 //   W : a dense column-fastest workspace view of one tile (own scratch), filled/drained here
-int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, bool want_zsat, int tile) {
+int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, bool want_zsat, int tile, int c_begin = 0,
+                      int c_end = -1) {
   const GridView& v = K.g;
   const obgc_bgc_params& P = h->bgc;
   const long long wl = W.g.sk;
   const int staged[10] = {P.ind[1], P.ind[3], P.ind[4], P.ind[2], P.ind[0], P.ind[14], P.ind[13], P.ind[6], P.ind[8], P.ind[5]};
-  for (int c0 = 0; c0 < v.ncol; c0 += tile) {
-    const int nc = (v.ncol - c0 < tile) ? (v.ncol - c0) : tile;
+  if (c_end < 0) c_end = v.ncol;
+  for (int c0 = c_begin; c0 < c_end; c0 += tile) {
+    const int nc = (c_end - c0 < tile) ? (c_end - c0) : tile;
     const long long off = (long long)c0 * v.sc;
     // ---- the caller's view of this tile
     BgcKernelArgs Kt = K;
@@ -513,7 +545,7 @@ int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, b
     tin.add(Kt.zmid, const_cast<double*>(Wt.zmid));
     tin.add(ktr(P.ind[1]), wtr(P.ind[1])); tin.add(ktr(P.ind[4]), wtr(P.ind[4])); tin.add(ktr(P.ind[5]), wtr(P.ind[5]));
     launch_transpose_table_k2c(tin, v.nlev, nc, v.sc, wl, h->s_main);
-    if (c0 == 0) HIP_TRY(h, hipEventRecord(h->ev_t0, h->s_main));
+    if (c0 == c_begin) HIP_TRY(h, hipEventRecord(h->ev_t0, h->s_main));
     // light: attenuation per cell (caller layout) -> scan per column (workspace) -> PAR entering each cell
     launch_bgc_att(Kt, P, h->s_main);
     PlaneTable t1; t1.n = 0; t1.add(kscr(S_ATT), wscr(S_ATT));
@@ -578,6 +610,99 @@ int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, b
 
 }  // namespace
 
+// Host-memory callers, reference layout: the call is bound by the PCIe link (1.8 GB up, 7.8 GB down at cfg2 with all
+// diagnostics against 5 ms of kernels), and the link is full duplex.  The columns are cut into chunks; this thread
+// uploads chunk i+1 while the GPU works on chunk i and a second thread downloads the results of chunk i-1 -- columns
+// are independent, so a chunk's outputs are final as soon as its kernels are.  A column range of one plane is one
+// contiguous piece of the reference layout.  Two threads because copies from pageable memory block their caller.
+int host_pipeline(obgc_handle* h, Stager& st, const GridView& v, const BgcKernelArgs& K, const BgcKernelArgs& W, bool want_zsat,
+                  int tile_cols, int nchunk) {
+  if (!h->s_up) HIP_TRY(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
+  if (!h->s_down) HIP_TRY(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
+  int chunk = (v.ncol + nchunk - 1) / nchunk;
+  chunk = (chunk + 63) / 64 * 64;
+  nchunk = (v.ncol + chunk - 1) / chunk;
+  std::vector<hipEvent_t> ev_up((size_t)nchunk, nullptr), ev_done((size_t)nchunk, nullptr);
+  hipError_t ce = hipSuccess;
+  for (int i = 0; i < nchunk && ce == hipSuccess; ++i) {
+    ce = hipEventCreateWithFlags(&ev_up[(size_t)i], hipEventDisableTiming);
+    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_done[(size_t)i], hipEventDisableTiming);
+  }
+  auto destroy_events = [&] {
+    for (auto e : ev_up) if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
+  };
+  if (ce != hipSuccess) { destroy_events(); return fail(h, OBGC_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(ce)); }
+
+  std::mutex m;
+  std::condition_variable cv;
+  int ready = 0;            // chunks whose kernels (and ev_done) are enqueued
+  bool stop = false;
+  hipError_t down_err = hipSuccess;
+  std::thread downloader([&] {
+    hipError_t e = hipSetDevice(h->device);
+    for (int i = 0; i < nchunk && e == hipSuccess; ++i) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return ready > i || stop; });
+        if (ready <= i) break;   // the producer gave up
+      }
+      const int c0 = i * chunk, c1 = (c0 + chunk < v.ncol) ? c0 + chunk : v.ncol;
+      e = hipStreamWaitEvent(h->s_down, ev_done[(size_t)i], 0);
+      for (size_t k = 0; k < st.items.size() && e == hipSuccess; ++k) {
+        const Stage& it = st.items[k];
+        if (!it.out || it.nplanes <= 0) continue;
+        for (int n = 0; n < it.nplanes && e == hipSuccess; ++n) {
+          size_t b, len;
+          chunk_range(it, v, n, c0, c1, b, len);
+          if (len) e = hipMemcpyAsync((char*)it.host + b, (char*)it.dev + b, len, hipMemcpyDeviceToHost, h->s_down);
+        }
+      }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->s_down);
+    down_err = e;
+  });
+
+  int rc = OBGC_OK;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < nchunk && e == hipSuccess && rc == OBGC_OK; ++i) {
+    const int c0 = i * chunk, c1 = (c0 + chunk < v.ncol) ? c0 + chunk : v.ncol;
+    for (size_t k = 0; k < st.items.size() && e == hipSuccess; ++k) {
+      const Stage& it = st.items[k];
+      if (!it.in || it.nplanes <= 0) continue;
+      for (int n = 0; n < it.nplanes && e == hipSuccess; ++n) {
+        size_t b, len;
+        chunk_range(it, v, n, c0, c1, b, len);
+        if (len) e = hipMemcpyAsync((char*)it.dev + b, (const char*)it.host + b, len, hipMemcpyHostToDevice, h->s_up);
+      }
+    }
+    if (e == hipSuccess) e = hipEventRecord(ev_up[(size_t)i], h->s_up);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->s_main, ev_up[(size_t)i], 0);
+    if (e != hipSuccess) break;
+    rc = bgc_launch_hybrid(h, K, W, want_zsat, tile_cols, c0, c1);
+    if (rc != OBGC_OK) break;
+    e = hipEventRecord(ev_done[(size_t)i], h->s_main);
+    if (e != hipSuccess) break;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      ready = i + 1;
+    }
+    cv.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(m);
+    stop = true;
+  }
+  cv.notify_one();
+  downloader.join();
+  (void)hipStreamSynchronize(h->s_main);
+  destroy_events();
+  if (rc != OBGC_OK) return rc;
+  if (e != hipSuccess) return fail(h, OBGC_ERR_HIP, std::string("host pipeline (upload): ") + hipGetErrorString(e));
+  if (down_err != hipSuccess) return fail(h, OBGC_ERR_HIP, std::string("host pipeline (download): ") + hipGetErrorString(down_err));
+  return OBGC_OK;
+}
+
 // ======================================================================== BGC_SourceSink ==
 
 extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_args* a) {
@@ -597,29 +722,34 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
 
   // ---- stage caller arrays (no-op for device memory) ----
   Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
-  const size_t kc1 = span_kc(v, 1);
-  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_BGC_NTRACER), true, false);
-  const int i_T = st.add(a->temp, kc1, true, false), i_S = st.add(a->salt, kc1, true, false);
-  const int i_zm = st.add(a->zmid, kc1, true, false), i_dz = st.add(a->dz, kc1, true, false);
-  const int i_zb = st.add(a->zbot, kc1, true, false), i_fs = st.add(a->fesedflux, kc1, true, false);
+  const int i_tr = st.add_kc(a->tracers, v, OBGC_BGC_NTRACER, true, false);
+  const int i_T = st.add_kc(a->temp, v, 1, true, false), i_S = st.add_kc(a->salt, v, 1, true, false);
+  const int i_zm = st.add_kc(a->zmid, v, 1, true, false), i_dz = st.add_kc(a->dz, v, 1, true, false);
+  const int i_zb = st.add_kc(a->zbot, v, 1, true, false), i_fs = st.add_kc(a->fesedflux, v, 1, true, false);
   const int i_lat = st.add(a->lat, v.ncol * sizeof(double), true, false);
   const int i_km = st.add(a->kmax, v.ncol * sizeof(int), true, false);
   const int i_du = st.add(a->dust_flux_in, v.ncol * sizeof(double), true, false);
   const int i_sw = st.add(a->sw_flux, v.ncol * sizeof(double), true, false);
   // the host path copies whole strided spans back, so outputs with gaps (ld > extent) are read in first
   const bool gaps = st.host && ((v.kfast ? v.sc != v.nlev : v.sk != v.ncol) || v.plane != (v.kfast ? v.sc * v.ncol : v.sk * v.nlev));
-  const int i_td = st.add(a->tend, span_kc(v, OBGC_BGC_NTRACER), gaps, true);
-  const int i_pp = st.add(a->ph_prev, kc1, true, true), i_pa = st.add(a->ph_prev_alt, kc1, true, true);
+  const int i_td = st.add_kc(a->tend, v, OBGC_BGC_NTRACER, gaps, true);
+  const int i_pp = st.add_kc(a->ph_prev, v, 1, true, true), i_pa = st.add_kc(a->ph_prev_alt, v, 1, true, true);
   obgc_bgc_diag dd;
   std::memset(&dd, 0, sizeof dd);
   std::vector<std::pair<double**, int>> dslots;
   if (a->diag) {
     const obgc_bgc_diag& D = *a->diag;
     const bool gaps_c = st.host && v.ldc != v.ncol;
-#define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, kc1, true, true)});
+    // every (k,column) diagnostic is written in full (values or the zero fill), so only padding has to be read in first;
+    // the three members neither the reference nor the engine touches do not travel at all
+#define X(n)                                                                                          \
+  if (D.n) {                                                                                          \
+    const bool untouched = &D.n == &D.POC_ACCUM || &D.n == &D.DONr_remin || &D.n == &D.DOPr_remin;   \
+    dslots.push_back({&dd.n, st.add_kc(D.n, v, 1, gaps && !untouched, !untouched)});                  \
+  }
     OBGC_BGC_DIAG_KC(X)
 #undef X
-#define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, span_kc(v, 4), gaps, true)});
+#define X(n) if (D.n) dslots.push_back({&dd.n, st.add_kc(D.n, v, 4, gaps, true)});
     OBGC_BGC_DIAG_KCA(X)
 #undef X
 #define X(n) if (D.n) dslots.push_back({&dd.n, st.add(D.n, span_c(v, 4), gaps_c, true)});
@@ -663,7 +793,9 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   }
   int rc = arena_reserve(h, (st.host ? st.need : 0) + work + scratch);
   if (rc != OBGC_OK) return rc;
-  rc = stage_in(h, st);
+  // host memory in the reference layout: overlap the two directions of the link and the kernels, chunk by chunk
+  const bool chunked = st.host && hybrid && h->host_chunks > 1 && v.ncol >= 64 * h->host_chunks && st.need >= h->host_pipeline_min_bytes;
+  rc = stage_in(h, st, chunked);
   if (rc != OBGC_OK) return rc;
   for (auto& s : dslots) *s.first = st.dev<double>(s.second);
 
@@ -710,7 +842,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
       OBGC_SWEEP_DIAG_KC(X)
 #undef X
     }
-    rc = bgc_launch_hybrid(h, K, W, want_zsat, tile_cols);
+    rc = chunked ? host_pipeline(h, st, v, K, W, want_zsat, tile_cols, h->host_chunks) : bgc_launch_hybrid(h, K, W, want_zsat, tile_cols);
     if (rc != OBGC_OK) return rc;
     h->tr_valid = true;
   } else {
@@ -777,7 +909,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   HIP_TRY(h, hipGetLastError());
   h->timed_valid = true;
 
-  rc = stage_out(h, st);
+  rc = stage_out(h, st, chunked);
   if (rc != OBGC_OK) return rc;
   return finish(h, st.host);
 }

@@ -201,6 +201,63 @@ def test_reference_layout_tiled_transposes(pkg, oracle, synth, monkeypatch):
     _assert(P.compare_bgc(a, oracle.bgc_source_sink(*args, z, z, diag_init=-7.0)), "tiled reference layout")
 
 
+def test_host_path_pipelined_in_column_chunks(pkg, synth, monkeypatch):
+    """Host-memory callers in the reference layout are served chunk by chunk (upload, kernels and download of
+    different column chunks overlap).  Force five chunks with a short last one, plain and with padded leading
+    dimensions, and require the bits of the one-piece path; the padding and the never-written members stay as they were."""
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    nc, nz = 1500, 23
+    syn = synth.generate(nc, nz, col0=31)
+    tr = synth.bgc_tracer_array(syn)
+    kc_names = ("temp", "salt", "zmid", "dz", "zbot", "fesed")
+
+    def run(eng, ld, extra):
+        plane = ld * (nc + extra)
+
+        def pad(x, npl):
+            buf = np.full((npl * plane,), np.nan)
+            view = np.lib.stride_tricks.as_strided(buf, (npl, nc, nz), (plane * 8, ld * 8, 8))
+            view[...] = np.asarray(x).reshape(npl, nc, nz)
+            return buf, view
+        t = {"tr": pad(tr, 30)}
+        for nm in kc_names:
+            t[nm] = pad(syn[nm], 1)
+        t["tend"] = pad(np.zeros((30, nc, nz)), 30)
+        t["php"], t["pha"] = pad(np.zeros((nc, nz)), 1), pad(np.zeros((nc, nz)), 1)
+        diag = {nm: pad(np.full((nc, nz), -7.0), 1) for nm in L.BGC_DIAG_KC}
+        diag.update({nm: pad(np.full((4, nc, nz), -7.0), 4) for nm in L.BGC_DIAG_KCA})
+        dvec = {nm: np.full((4, nc), -7.0) for nm in L.BGC_DIAG_CA}
+        dvec.update({nm: np.full((nc,), -7.0) for nm in L.BGC_DIAG_C})
+        d = {nm: b for nm, (b, _) in diag.items()}
+        d.update(dvec)
+        eng.bgc_source_sink(nz, nc, L.OBGC_LAYOUT_KFAST, t["tr"][0], *(t[nm][0] for nm in kc_names[:5]), syn["lat"],
+                            syn["kmax"], t["fesed"][0], syn["dust"], syn["sw"], t["tend"][0], t["php"][0], t["pha"][0], d, True,
+                            ld=ld, plane=plane)
+        out = {"tend": t["tend"], "php": t["php"], "pha": t["pha"]}
+        out.update(diag)
+        return out, dvec
+
+    monkeypatch.setenv("OBGC_HOST_CHUNKS", "0")
+    one = Engine(0)
+    monkeypatch.setenv("OBGC_HOST_CHUNKS", "5")
+    monkeypatch.setenv("OBGC_HOST_PIPELINE_MIN_MB", "0")
+    piped = Engine(0)
+    for ld, extra in ((nz, 0), (nz + 3, 2)):
+        a, av = run(one, ld, extra)
+        b, bv = run(piped, ld, extra)
+        for nm in a:
+            assert np.array_equal(a[nm][0], b[nm][0], equal_nan=True), (ld, nm)          # whole buffers, padding included
+            inside = np.zeros(a[nm][0].shape, dtype=bool)
+            np.lib.stride_tricks.as_strided(inside, a[nm][1].shape, tuple(s // 8 for s in a[nm][1].strides))[...] = True
+            assert np.isnan(b[nm][0][~inside]).all(), (ld, nm)
+        for nm in av:
+            assert np.array_equal(av[nm], bv[nm]), nm
+        for nm in L.BGC_DIAG_KC_UNTOUCHED:
+            assert (b[nm][1] == -7.0).all(), nm
+        assert not (b["tend"][1] == 0).all()
+
+
 @pytest.mark.parametrize("layout", ["colfast", "kfast"])
 def test_padded_strides_leave_the_padding_alone(pkg, synth, layout):
     """Callers may pass arrays larger than the batch (ld > extent, plane > ld*extent; the reference's
