@@ -2,7 +2,11 @@
 // ocean model's conventions come in, the layout change / unit conversions run here, the path runs in its native
 // layout through the library's own entry points, thickness-weighted tendencies go back.  Arithmetic of the packing
 // is the Fortran adapter's (ocean-bgc_amd/fortran/obgc_mpas_adapter.F90), operation for operation.
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "obgc_internal.h"
@@ -19,6 +23,11 @@ struct obgc_block {
   // staging of the model's arrays (model layout)
   double *m_tr, *m_h, *m_zmid, *m_t, *m_s, *m_fesed, *m_tend, *m_sflux, *m_c[8], *m_flux[3];
   int* m_kmax;
+  // pipelined step: cell chunks, results of chunk i go down on s_down while chunk i+1 comes up on the engine's stream
+  enum { kMaxChunks = 16 };
+  int chunks = 8, min_cells = 8192;
+  hipStream_t s_down = nullptr;
+  hipEvent_t ev_done[kMaxChunks] = {};
 };
 
 namespace obgc {
@@ -29,7 +38,9 @@ constexpr double M_TO_CM = 100.0, CM_TO_M = 0.01, PA_TO_ATM = 1.0 / 101325.0, RA
                  KGM2S_TO_GCM2S = 0.1;
 
 // (n, k, c) tracer-fastest  ->  [n][k][c]; one workgroup per (64 columns, level)
-__global__ __launch_bounds__(256) void block_pack_tracers_kernel(const double* __restrict__ src, double* __restrict__ dst, int nz, int nc) {
+// `nc` cells starting at the pointers; `ld` = cells of the whole block (row stride and plane size of the native arrays)
+__global__ __launch_bounds__(256) void block_pack_tracers_kernel(const double* __restrict__ src, double* __restrict__ dst, int nz, int nc,
+                                                                 long long ld) {
   __shared__ double tile[NT][65];
   const int c0 = blockIdx.x * 64, k = blockIdx.y;
   for (int i = threadIdx.x; i < 64 * NT; i += 256) {
@@ -39,7 +50,7 @@ __global__ __launch_bounds__(256) void block_pack_tracers_kernel(const double* _
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * NT; i += 256) {
     const int n = i >> 6, cl = i & 63;
-    if (c0 + cl < nc) dst[((long long)n * nz + k) * nc + c0 + cl] = tile[n][cl];
+    if (c0 + cl < nc) dst[((long long)n * nz + k) * ld + c0 + cl] = tile[n][cl];
   }
 }
 
@@ -47,12 +58,12 @@ __global__ __launch_bounds__(256) void block_pack_tracers_kernel(const double* _
 // when accumulating, zero otherwise
 __global__ __launch_bounds__(256) void block_unpack_tend_kernel(const double* __restrict__ tend, const double* __restrict__ h_kc,
                                                                const int* __restrict__ kmax, double* __restrict__ out, int nz, int nc,
-                                                               int accumulate) {
+                                                               long long ld, int accumulate) {
   __shared__ double tile[NT][65];
   const int c0 = blockIdx.x * 64, k = blockIdx.y;
   for (int i = threadIdx.x; i < 64 * NT; i += 256) {
     const int n = i >> 6, cl = i & 63;
-    if (c0 + cl < nc) tile[n][cl] = tend[((long long)n * nz + k) * nc + c0 + cl];
+    if (c0 + cl < nc) tile[n][cl] = tend[((long long)n * nz + k) * ld + c0 + cl];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * NT; i += 256) {
@@ -70,6 +81,7 @@ __global__ __launch_bounds__(256) void block_unpack_tend_kernel(const double* __
 // per column: level-dependent fields (level-fastest model arrays -> native), cumulative bottom depth, forcing
 struct PackArgs {
   int nz, nc;
+  long long ld;
   const double *h, *zmid, *t, *s, *fesed, *lat, *swf, *patm, *ice, *wind, *co2, *co2alt, *dustf;
   double *dz, *o_zmid, *zbot, *o_t, *o_s, *o_fesed, *o_lat, *o_sw, *o_patm, *o_ice, *o_wind, *o_co2, *o_co2alt, *o_dust, *sdepth,
       *sst, *sss;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(64) void block_pack_fields_kernel(PackArgs a) {
   if (c >= a.nc) return;
   double zb = 0.0;
   for (int k = 0; k < a.nz; ++k) {
-    const long long m = (long long)c * a.nz + k, n = (long long)k * a.nc + c;
+    const long long m = (long long)c * a.nz + k, n = (long long)k * a.ld + c;
     const double hk = a.h[m];
     a.dz[n] = hk * M_TO_CM;
     a.o_zmid[n] = -a.zmid[m] * M_TO_CM;
@@ -104,11 +116,11 @@ __global__ __launch_bounds__(64) void block_pack_fields_kernel(PackArgs a) {
 }
 
 // (c, n) model flux arrays are already (column, tracer) column-fastest; surface flux out: (n, c) tracer-fastest
-__global__ __launch_bounds__(256) void block_sflux_kernel(const double* __restrict__ net, double* __restrict__ out, int nc) {
+__global__ __launch_bounds__(256) void block_sflux_kernel(const double* __restrict__ net, double* __restrict__ out, int nc, long long ld) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)nc * NT) return;
   const int c = (int)(i / NT), n = (int)(i - (long long)c * NT);
-  out[i] = net[(long long)n * nc + c] * CM_TO_M;
+  out[i] = net[(long long)n * ld + c] * CM_TO_M;
 }
 
 }  // namespace
@@ -149,6 +161,13 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
   (void)hipMemsetAsync(b->sph, 0, nc * d, st); (void)hipMemsetAsync(b->spha, 0, nc * d, st);
   (void)hipMemsetAsync(b->gas, 0, NT * nc * d, st);
   if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(b->pool); delete b; return OBGC_ERR_HIP; }
+  if (const char* e = std::getenv("OBGC_BLOCK_CHUNKS")) b->chunks = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_BLOCK_MIN_CELLS")) b->min_cells = std::atoi(e);
+  if (b->chunks < 1) b->chunks = 1;
+  if (b->chunks > obgc_block::kMaxChunks) b->chunks = obgc_block::kMaxChunks;
+  bool ok = hipStreamCreateWithFlags(&b->s_down, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < obgc_block::kMaxChunks && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { (void)obgc_block_destroy(b); return OBGC_ERR_HIP; }
   *out = b;
   return OBGC_OK;
 }
@@ -156,11 +175,90 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
 extern "C" int obgc_block_destroy(obgc_block* b) {
   if (!b) return OBGC_ERR_INVALID;
   (void)obgc_sync(b->h);
+  if (b->s_down) (void)hipStreamDestroy(b->s_down);
+  for (hipEvent_t e : b->ev_done) if (e) (void)hipEventDestroy(e);
   (void)hipFree(b->pool);
   delete b;
   return OBGC_OK;
 }
 
+namespace {
+
+// cells [c0, c1) of the block: upload their slices, pack, BGC_SurfaceFluxes + BGC_SourceSink on the native arrays (a
+// column range of a column-fastest array is the same array with an offset and the block's row stride), unpack
+int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c1) {
+  const int ncb = b->nc, nz = b->nz, n = c1 - c0;
+  const size_t d = sizeof(double);
+  const size_t kc0 = (size_t)c0 * nz, kcn = (size_t)n * nz;
+  hipStream_t st = (hipStream_t)obgc_stream(b->h);
+#define UP(dst, src, bytes) if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return OBGC_ERR_HIP;
+  UP(b->m_tr + NT * kc0, a->ecosysTracers + NT * kc0, NT * kcn * d)
+  UP(b->m_h + kc0, a->layerThickness + kc0, kcn * d) UP(b->m_zmid + kc0, a->zMid + kc0, kcn * d)
+  UP(b->m_t + kc0, a->temperature + kc0, kcn * d) UP(b->m_s + kc0, a->salinity + kc0, kcn * d)
+  UP(b->m_fesed + kc0, a->ironSedimentFlux + kc0, kcn * d)
+  if (a->accumulate) UP(b->m_tend + NT * kc0, a->ecosysTracersTend + NT * kc0, NT * kcn * d)
+#undef UP
+  hipLaunchKernelGGL(block_pack_tracers_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->m_tr + NT * kc0, b->tracers + c0, nz, n,
+                     (long long)ncb);
+  PackArgs pa;
+  pa.nz = nz; pa.nc = n; pa.ld = ncb;
+  pa.h = b->m_h + kc0; pa.zmid = b->m_zmid + kc0; pa.t = b->m_t + kc0; pa.s = b->m_s + kc0; pa.fesed = b->m_fesed + kc0;
+  pa.lat = b->m_c[0] + c0; pa.swf = b->m_c[1] + c0; pa.patm = b->m_c[2] + c0; pa.ice = b->m_c[3] + c0; pa.wind = b->m_c[4] + c0;
+  pa.co2 = b->m_c[5] + c0; pa.co2alt = b->m_c[6] + c0; pa.dustf = b->m_c[7] + c0;
+  pa.dz = b->dz + c0; pa.o_zmid = b->zmid + c0; pa.zbot = b->zbot + c0; pa.o_t = b->temp + c0; pa.o_s = b->salt + c0;
+  pa.o_fesed = b->fesed + c0;
+  pa.o_lat = b->lat + c0; pa.o_sw = b->sw + c0; pa.o_patm = b->patm + c0; pa.o_ice = b->ice + c0; pa.o_wind = b->wind + c0;
+  pa.o_co2 = b->co2 + c0; pa.o_co2alt = b->co2alt + c0; pa.o_dust = b->dust + c0; pa.sdepth = b->sdepth + c0; pa.sst = b->sst + c0;
+  pa.sss = b->sss + c0;
+  hipLaunchKernelGGL(block_pack_fields_kernel, dim3((n + 63) / 64), dim3(64), 0, st, pa);
+  if (hipGetLastError() != hipSuccess) return OBGC_ERR_HIP;
+
+  obgc_grid g;
+  std::memset(&g, 0, sizeof g);
+  g.nlev = nz; g.ncol = n; g.layout = OBGC_LAYOUT_COLFAST; g.memspace = OBGC_MEM_DEVICE;
+  g.ld = ncb; g.plane = (long long)ncb * nz; g.ldc = ncb;
+  obgc_bgc_surface_fluxes_args sf;
+  std::memset(&sf, 0, sizeof sf);
+  sf.grid = g; sf.tracers = b->tracers + c0;
+  sf.surfacePressure = b->patm + c0; sf.windSpeedSquared10m = b->wind + c0; sf.atmCO2 = b->co2 + c0;
+  sf.atmCO2_ALT_CO2 = b->co2alt + c0;
+  sf.surfaceDepth = b->sdepth + c0; sf.SST = b->sst + c0; sf.SSS = b->sss + c0; sf.iceFraction = b->ice + c0;
+  sf.surface_pH = b->sph + c0; sf.surface_pH_alt_co2 = b->spha + c0;
+  sf.depositionFlux = b->depo + c0; sf.riverFlux = b->river + c0; sf.gasFlux = b->gas + c0; sf.seaIceFlux = b->seaice + c0;
+  sf.netFlux = b->net + c0;
+  sf.lcalc_O2_gas_flux = 1; sf.lcalc_CO2_gas_flux = 1;
+  int rc = obgc_bgc_surface_fluxes(b->h, &sf);
+  if (rc != OBGC_OK) return rc;
+  obgc_bgc_source_sink_args ss;
+  std::memset(&ss, 0, sizeof ss);
+  ss.grid = g; ss.tracers = b->tracers + c0; ss.temp = b->temp + c0; ss.salt = b->salt + c0; ss.zmid = b->zmid + c0;
+  ss.dz = b->dz + c0; ss.zbot = b->zbot + c0;
+  ss.lat = b->lat + c0; ss.kmax = b->kmax + c0; ss.fesedflux = b->fesed + c0; ss.dust_flux_in = b->dust + c0; ss.sw_flux = b->sw + c0;
+  ss.tend = b->tend + c0; ss.ph_prev = b->php + c0; ss.ph_prev_alt = b->pha + c0; ss.diag = nullptr; ss.alt_co2_use_eco = 0;
+  rc = obgc_bgc_source_sink(b->h, &ss);
+  if (rc != OBGC_OK) return rc;
+
+  hipLaunchKernelGGL(block_unpack_tend_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->tend + c0, b->m_h + kc0, b->kmax + c0,
+                     b->m_tend + NT * kc0, nz, n, (long long)ncb, a->accumulate ? 1 : 0);
+  hipLaunchKernelGGL(block_sflux_kernel, dim3((unsigned)(((long long)n * NT + 255) / 256)), dim3(256), 0, st, b->net + c0,
+                     b->m_sflux + (size_t)NT * c0, n, (long long)ncb);
+  return hipGetLastError() == hipSuccess ? OBGC_OK : OBGC_ERR_HIP;
+}
+
+hipError_t block_download_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c1, hipStream_t st) {
+  const size_t d = sizeof(double), kc0 = (size_t)c0 * b->nz, kcn = (size_t)(c1 - c0) * b->nz;
+  hipError_t e = hipMemcpyAsync(a->ecosysTracersTend + NT * kc0, b->m_tend + NT * kc0, NT * kcn * d, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(a->ecosysSurfaceFlux + (size_t)NT * c0, b->m_sflux + (size_t)NT * c0, NT * (size_t)(c1 - c0) * d,
+                       hipMemcpyDeviceToHost, st);
+  return e;
+}
+
+}  // namespace
+
+// The step is bound by the link (1.7 GB up, 1.4 GB down at 100k x 60 against 2.5 ms of kernels): cells are independent,
+// so the block is cut into `chunks` cell ranges (OBGC_BLOCK_CHUNKS, default 8; blocks below OBGC_BLOCK_MIN_CELLS = 8192 cells stay whole) and a
+// second thread sends the results of range i down while this one brings range i+1 up.
 extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   if (!b || !a) return OBGC_ERR_INVALID;
   if (!a->ecosysTracers || !a->layerThickness || !a->zMid || !a->temperature || !a->salinity || !a->maxLevelCell || !a->latCell ||
@@ -168,13 +266,11 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
       !a->atmosphericCO2_ALT_CO2 || !a->dustFlux || !a->ironSedimentFlux || !a->depositionFlux || !a->riverFlux || !a->seaIceFlux ||
       !a->ecosysTracersTend || !a->ecosysSurfaceFlux)
     return OBGC_ERR_INVALID;
-  const int nc = b->nc, nz = b->nz;
-  const size_t d = sizeof(double), kc = (size_t)nc * nz;
+  const int nc = b->nc;
+  const size_t d = sizeof(double);
   hipStream_t st = (hipStream_t)obgc_stream(b->h);
+  // per-cell arrays: small, whole block at once
 #define UP(dst, src, bytes) if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return OBGC_ERR_HIP;
-  UP(b->m_tr, a->ecosysTracers, NT * kc * d)
-  UP(b->m_h, a->layerThickness, kc * d) UP(b->m_zmid, a->zMid, kc * d) UP(b->m_t, a->temperature, kc * d)
-  UP(b->m_s, a->salinity, kc * d) UP(b->m_fesed, a->ironSedimentFlux, kc * d)
   const double* cols[8] = {a->latCell, a->shortWaveHeatFlux, a->atmosphericPressure, a->iceFraction, a->windSpeedSquared10m,
                            a->atmosphericCO2, a->atmosphericCO2_ALT_CO2, a->dustFlux};
   for (int i = 0; i < 8; ++i) UP(b->m_c[i], cols[i], (size_t)nc * d)
@@ -182,46 +278,58 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   // the three flux arrays are re-uploaded every step: the package scales their Fe rows in place
   UP(b->depo, a->depositionFlux, NT * (size_t)nc * d) UP(b->river, a->riverFlux, NT * (size_t)nc * d)
   UP(b->seaice, a->seaIceFlux, NT * (size_t)nc * d)
-  if (a->accumulate) UP(b->m_tend, a->ecosysTracersTend, NT * kc * d)
 #undef UP
-  hipLaunchKernelGGL(block_pack_tracers_kernel, dim3((nc + 63) / 64, nz), dim3(256), 0, st, b->m_tr, b->tracers, nz, nc);
-  PackArgs pa;
-  pa.nz = nz; pa.nc = nc;
-  pa.h = b->m_h; pa.zmid = b->m_zmid; pa.t = b->m_t; pa.s = b->m_s; pa.fesed = b->m_fesed;
-  pa.lat = b->m_c[0]; pa.swf = b->m_c[1]; pa.patm = b->m_c[2]; pa.ice = b->m_c[3]; pa.wind = b->m_c[4]; pa.co2 = b->m_c[5];
-  pa.co2alt = b->m_c[6]; pa.dustf = b->m_c[7];
-  pa.dz = b->dz; pa.o_zmid = b->zmid; pa.zbot = b->zbot; pa.o_t = b->temp; pa.o_s = b->salt; pa.o_fesed = b->fesed;
-  pa.o_lat = b->lat; pa.o_sw = b->sw; pa.o_patm = b->patm; pa.o_ice = b->ice; pa.o_wind = b->wind; pa.o_co2 = b->co2;
-  pa.o_co2alt = b->co2alt; pa.o_dust = b->dust; pa.sdepth = b->sdepth; pa.sst = b->sst; pa.sss = b->sss;
-  hipLaunchKernelGGL(block_pack_fields_kernel, dim3((nc + 63) / 64), dim3(64), 0, st, pa);
-  if (hipGetLastError() != hipSuccess) return OBGC_ERR_HIP;
+  int nchunk = nc >= b->min_cells ? b->chunks : 1;
+  int chunk = ((nc + nchunk - 1) / nchunk + 63) / 64 * 64;
+  nchunk = (nc + chunk - 1) / chunk;
+  if (nchunk == 1) {
+    int rc = block_step_range(b, a, 0, nc);
+    if (rc != OBGC_OK) return rc;
+    if (block_download_range(b, a, 0, nc, st) != hipSuccess) return OBGC_ERR_HIP;
+    return hipStreamSynchronize(st) == hipSuccess ? OBGC_OK : OBGC_ERR_HIP;
+  }
 
-  obgc_grid g;
-  std::memset(&g, 0, sizeof g);
-  g.nlev = nz; g.ncol = nc; g.layout = OBGC_LAYOUT_COLFAST; g.memspace = OBGC_MEM_DEVICE;
-  obgc_bgc_surface_fluxes_args sf;
-  std::memset(&sf, 0, sizeof sf);
-  sf.grid = g; sf.tracers = b->tracers;
-  sf.surfacePressure = b->patm; sf.windSpeedSquared10m = b->wind; sf.atmCO2 = b->co2; sf.atmCO2_ALT_CO2 = b->co2alt;
-  sf.surfaceDepth = b->sdepth; sf.SST = b->sst; sf.SSS = b->sss; sf.iceFraction = b->ice;
-  sf.surface_pH = b->sph; sf.surface_pH_alt_co2 = b->spha;
-  sf.depositionFlux = b->depo; sf.riverFlux = b->river; sf.gasFlux = b->gas; sf.seaIceFlux = b->seaice; sf.netFlux = b->net;
-  sf.lcalc_O2_gas_flux = 1; sf.lcalc_CO2_gas_flux = 1;
-  int rc = obgc_bgc_surface_fluxes(b->h, &sf);
-  if (rc != OBGC_OK) return rc;
-  obgc_bgc_source_sink_args ss;
-  std::memset(&ss, 0, sizeof ss);
-  ss.grid = g; ss.tracers = b->tracers; ss.temp = b->temp; ss.salt = b->salt; ss.zmid = b->zmid; ss.dz = b->dz; ss.zbot = b->zbot;
-  ss.lat = b->lat; ss.kmax = b->kmax; ss.fesedflux = b->fesed; ss.dust_flux_in = b->dust; ss.sw_flux = b->sw;
-  ss.tend = b->tend; ss.ph_prev = b->php; ss.ph_prev_alt = b->pha; ss.diag = nullptr; ss.alt_co2_use_eco = 0;
-  rc = obgc_bgc_source_sink(b->h, &ss);
-  if (rc != OBGC_OK) return rc;
-
-  hipLaunchKernelGGL(block_unpack_tend_kernel, dim3((nc + 63) / 64, nz), dim3(256), 0, st, b->tend, b->m_h, b->kmax, b->m_tend, nz, nc,
-                     a->accumulate ? 1 : 0);
-  hipLaunchKernelGGL(block_sflux_kernel, dim3((unsigned)(((long long)nc * NT + 255) / 256)), dim3(256), 0, st, b->net, b->m_sflux, nc);
-  if (hipGetLastError() != hipSuccess) return OBGC_ERR_HIP;
-  if (hipMemcpyAsync(a->ecosysTracersTend, b->m_tend, NT * kc * d, hipMemcpyDeviceToHost, st) != hipSuccess) return OBGC_ERR_HIP;
-  if (hipMemcpyAsync(a->ecosysSurfaceFlux, b->m_sflux, NT * (size_t)nc * d, hipMemcpyDeviceToHost, st) != hipSuccess) return OBGC_ERR_HIP;
-  return hipStreamSynchronize(st) == hipSuccess ? OBGC_OK : OBGC_ERR_HIP;
+  std::mutex m;
+  std::condition_variable cv;
+  int ready = 0;
+  bool stop = false;
+  hipError_t down_err = hipSuccess;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::thread downloader([&] {
+    hipError_t e = hipSetDevice(device);
+    for (int i = 0; i < nchunk && e == hipSuccess; ++i) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return ready > i || stop; });
+        if (ready <= i) break;
+      }
+      const int c0 = i * chunk, c1 = (c0 + chunk < nc) ? c0 + chunk : nc;
+      e = hipStreamWaitEvent(b->s_down, b->ev_done[i], 0);
+      if (e == hipSuccess) e = block_download_range(b, a, c0, c1, b->s_down);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(b->s_down);
+    down_err = e;
+  });
+  int rc = OBGC_OK;
+  for (int i = 0; i < nchunk && rc == OBGC_OK; ++i) {
+    const int c0 = i * chunk, c1 = (c0 + chunk < nc) ? c0 + chunk : nc;
+    rc = block_step_range(b, a, c0, c1);
+    if (rc == OBGC_OK && hipEventRecord(b->ev_done[i], st) != hipSuccess) rc = OBGC_ERR_HIP;
+    if (rc != OBGC_OK) break;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      ready = i + 1;
+    }
+    cv.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(m);
+    stop = true;
+  }
+  cv.notify_one();
+  downloader.join();
+  if (hipStreamSynchronize(st) != hipSuccess && rc == OBGC_OK) rc = OBGC_ERR_HIP;
+  if (rc == OBGC_OK && down_err != hipSuccess) rc = OBGC_ERR_HIP;
+  return rc;
 }

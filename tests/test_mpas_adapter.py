@@ -165,7 +165,8 @@ def test_adapter_on_gpu_batched_equals_per_cell_and_matches_oracle(tmp_path, syn
     assert rep.ok(), "\n".join(rep.fail[:10])
 
 
-def block_step(L, eng, blk, m, nc, nz, tend, accumulate):
+def block_args(L, m, nc, nz, tend, accumulate):
+    """-> (obgc_block_step_args, arrays it points to, the surface-flux output array)"""
     import ctypes as C
     a = L.BlockStepArgs()
     keep = []
@@ -187,18 +188,28 @@ def block_step(L, eng, blk, m, nc, nz, tend, accumulate):
     a.ecosysTracersTend = tend.ctypes.data_as(C.c_void_p)
     a.ecosysSurfaceFlux = sflux.ctypes.data_as(C.c_void_p)
     a.accumulate = 1 if accumulate else 0
+    return a, keep, sflux
+
+
+def block_step(L, eng, blk, m, nc, nz, tend, accumulate):
+    import ctypes as C
+    a, keep, sflux = block_args(L, m, nc, nz, tend, accumulate)
     rc = eng.lib.obgc_block_step(blk, C.byref(a))
     assert rc == 0, (rc, eng.lib.obgc_last_error(eng.h))
     return sflux
 
 
 @pytest.mark.gpu
-def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, oracle, pkg):
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, oracle, pkg, monkeypatch, chunks):
     """The device-resident block (obgc_block_*): same bits as the Fortran adapter through the host path, parity bars
-    against the numpy + oracle restatement, and the accumulate switch."""
+    against the numpy + oracle restatement, and the accumulate switch.  chunks = 3: the pipelined step (cell ranges
+    of 256, 256 and 128 cells going up, through the kernels and down concurrently)."""
     import ctypes as C
     if not has_gpu():
         pytest.fail("needs a GPU")
+    monkeypatch.setenv("OBGC_BLOCK_CHUNKS", str(chunks))
+    monkeypatch.setenv("OBGC_BLOCK_MIN_CELLS", "0")
     if not os.path.exists(EXE_GPU):
         subprocess.check_call(["make", "-s", "-C", FDIR])
     from ocean_bgc_amd import _lib as L

@@ -8,7 +8,7 @@ from __graft_entry__ import load_pkg
 load_pkg()
 from ocean_bgc_amd import _lib as L, synth
 from ocean_bgc_amd.engine import Engine
-from test_mpas_adapter import mpas_block, block_step
+from test_mpas_adapter import mpas_block, block_args
 nc, nz = 100000, 60
 m, pk = mpas_block(synth, nc, nz, col0=0)
 E = Engine(0)
@@ -18,8 +18,9 @@ tend = np.zeros((nc, nz, 30))
 cells = int(m["kmax"].clip(0, nz).sum())
 for acc in (False, True):
     ts = []
-    for i in range(4):
+    a, keep, sflux = block_args(L, m, nc, nz, tend, acc)      # the model's arrays as they are: nothing is converted per step
+    for i in range(5):
         t0 = time.perf_counter()
-        block_step(L, E, blk, m, nc, nz, tend, acc)
+        assert E.lib.obgc_block_step(blk, C.byref(a)) == 0
         ts.append(time.perf_counter() - t0)
     print("resident block step, accumulate=%s: best %.1f ms -> %.3e updates/s (PCIe-inclusive)" % (acc, 1e3 * min(ts[1:]), 30 * cells / min(ts[1:])), flush=True)
