@@ -914,6 +914,38 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   return finish(h, st.host);
 }
 
+// *_SurfaceFluxes read the surface row of a few tracers (BGC_mod.F90:2816-2822, DMS_mod.F90:834).  A host-memory caller
+// therefore does not ship the (k,column,n) array: the rows are gathered on the host into `rows` (slot-major, dense in
+// the column) and land in a device array that the kernel addresses as a one-level, column-fastest tracer array.
+struct SurfaceRows {
+  std::vector<double> rows;   // alive until the call has synchronised
+  int item = -1;              // Stager item of the device copy (ntracer x ncol doubles, only the gathered slots are filled)
+};
+
+void gather_surface_rows(Stager& st, const GridView& v, const double* tracers, int ntracer, const int* slots, int nslots,
+                         SurfaceRows& out) {
+  out.rows.resize((size_t)nslots * (size_t)v.ncol);
+  for (int i = 0; i < nslots; ++i) {
+    const double* src = tracers + (long long)(slots[i] - 1) * v.plane;
+    double* dst = out.rows.data() + (size_t)i * (size_t)v.ncol;
+    for (int c = 0; c < v.ncol; ++c) dst[c] = src[v.at(0, c)];
+  }
+  out.item = st.add(out.rows.data(), (size_t)ntracer * (size_t)v.ncol * sizeof(double), false, false);   // device room only
+}
+
+int upload_surface_rows(obgc_handle* h, const Stager& st, const GridView& v, const int* slots, int nslots, const SurfaceRows& r) {
+  double* dev = st.dev<double>(r.item);
+  for (int i = 0; i < nslots; ++i)
+    HIP_TRY(h, hipMemcpyAsync(dev + (size_t)(slots[i] - 1) * (size_t)v.ncol, r.rows.data() + (size_t)i * (size_t)v.ncol,
+                              (size_t)v.ncol * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+  return OBGC_OK;
+}
+
+inline GridView surface_rows_view(GridView v) {
+  v.kfast = 0; v.nlev = 1; v.sc = 1; v.sk = v.ncol; v.plane = v.ncol;   // ldc stays the caller's
+  return v;
+}
+
 // ===================================================================== BGC_SurfaceFluxes ==
 
 extern "C" int obgc_bgc_surface_fluxes(obgc_handle* h, const obgc_bgc_surface_fluxes_args* a) {
@@ -931,7 +963,11 @@ extern "C" int obgc_bgc_surface_fluxes(obgc_handle* h, const obgc_bgc_surface_fl
   h->timed_valid = false;
   Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
   const size_t cb = v.ncol * sizeof(double), fb = span_c(v, OBGC_BGC_NTRACER);
-  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_BGC_NTRACER), true, false);
+  const int surf_slots[6] = {h->bgc.ind[6], h->bgc.ind[7], h->bgc.ind[8], h->bgc.ind[0], h->bgc.ind[2], h->bgc.ind[5]};
+  SurfaceRows srows;
+  int i_tr;
+  if (st.host) { gather_surface_rows(st, v, a->tracers, OBGC_BGC_NTRACER, surf_slots, 6, srows); i_tr = srows.item; }
+  else i_tr = st.add(a->tracers, span_kc(v, OBGC_BGC_NTRACER), true, false);
   const int i_p = st.add(a->surfacePressure, cb, true, false), i_w = st.add(a->windSpeedSquared10m, cb, true, false);
   const int i_c1 = st.add(a->atmCO2, cb, true, false), i_c2 = st.add(a->atmCO2_ALT_CO2, cb, true, false);
   const int i_sd = st.add(a->surfaceDepth, cb, true, false), i_t = st.add(a->SST, cb, true, false);
@@ -954,6 +990,11 @@ extern "C" int obgc_bgc_surface_fluxes(obgc_handle* h, const obgc_bgc_surface_fl
   SurfKernelArgs K;
   std::memset(&K, 0, sizeof K);
   K.g = v;
+  if (st.host) {
+    rc = upload_surface_rows(h, st, v, surf_slots, 6, srows);
+    if (rc != OBGC_OK) return rc;
+    K.g = surface_rows_view(v);
+  }
   K.tracers = st.dev<const double>(i_tr);
   K.surfacePressure = st.dev<const double>(i_p); K.wind2 = st.dev<const double>(i_w); K.atmCO2 = st.dev<const double>(i_c1);
   K.atmCO2_alt = st.dev<const double>(i_c2); K.surfaceDepth = st.dev<const double>(i_sd); K.SST = st.dev<const double>(i_t);
@@ -1056,7 +1097,11 @@ extern "C" int obgc_dms_surface_fluxes(obgc_handle* h, const obgc_dms_surface_fl
   h->timed_valid = false;
   Stager st(h, a->grid.memspace == OBGC_MEM_HOST);
   const size_t cb = v.ncol * sizeof(double);
-  const int i_tr = st.add(a->tracers, span_kc(v, OBGC_DMS_NTRACER), true, false);
+  const int surf_slots[1] = {h->dms.ind[0]};   // seaSurfaceDMS is the only tracer value read (DMS_mod.F90:834)
+  SurfaceRows srows;
+  int i_tr;
+  if (st.host) { gather_surface_rows(st, v, a->tracers, OBGC_DMS_NTRACER, surf_slots, 1, srows); i_tr = srows.item; }
+  else i_tr = st.add(a->tracers, span_kc(v, OBGC_DMS_NTRACER), true, false);
   const int i_p = st.add(a->surfacePressure, cb, true, false), i_w = st.add(a->windSpeedSquared10m, cb, true, false);
   const int i_t = st.add(a->SST, cb, true, false), i_ice = st.add(a->iceFraction, cb, true, true);
   const int i_ne = st.add(a->netFlux, span_c(v, OBGC_DMS_NTRACER), true, true);   // only two rows are written
@@ -1074,6 +1119,11 @@ extern "C" int obgc_dms_surface_fluxes(obgc_handle* h, const obgc_dms_surface_fl
   DmsSurfKernelArgs K;
   std::memset(&K, 0, sizeof K);
   K.g = v;
+  if (st.host) {
+    rc = upload_surface_rows(h, st, v, surf_slots, 1, srows);
+    if (rc != OBGC_OK) return rc;
+    K.g = surface_rows_view(v);
+  }
   K.tracers = st.dev<const double>(i_tr); K.surfacePressure = st.dev<const double>(i_p); K.wind2 = st.dev<const double>(i_w);
   K.SST = st.dev<const double>(i_t); K.iceFraction = st.dev<double>(i_ice); K.net = st.dev<double>(i_ne);
   K.diag = dd;

@@ -23,3 +23,15 @@ for dg, name in ((diag, "full"), (None, "none")):
         eng.bgc_source_sink(nz, nc, L.OBGC_LAYOUT_KFAST, tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"], syn["sw"], tend, ph[0], ph[1], dg, True)
         ts.append(time.perf_counter() - t0)
     print("host path", name, "best %.1f ms -> %.3e updates/s (PCIe-inclusive, pageable host memory)" % (1e3 * min(ts), 30 * cells / min(ts)), flush=True)
+
+# BGC_SurfaceFluxes through host memory: only the surface rows of six tracers travel, not the (k,column,n) array
+f = {k: v.copy() for k, v in syn["forcing"].items()}
+fl = [syn[nm].copy() for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")]
+net = np.zeros((30, nc))
+fd = {nm: np.zeros(nc) for nm in L.BGC_FLUX_DIAG}
+ts = []
+for i in range(4):
+    t0 = time.perf_counter()
+    eng.bgc_surface_fluxes(nz, nc, L.OBGC_LAYOUT_KFAST, tr, f, *fl, net, fd)
+    ts.append(time.perf_counter() - t0)
+print("host path BGC_SurfaceFluxes best %.1f ms (%d columns)" % (1e3 * min(ts), nc), flush=True)
