@@ -172,3 +172,44 @@ def test_async_handle_orders_its_own_work(pkg, synth):
     a, b = run(0), run(L.OBGC_ASYNC if hasattr(L, "OBGC_ASYNC") else 1)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_two_host_threads_with_their_own_handles(pkg, synth, monkeypatch):
+    """The reference is not re-entrant (co2calc.F90:65-67 keeps module state); the engine's contract is one handle per
+    host thread (include/obgc.h).  Two threads, each with its own handle on the same GPU, run different batches
+    concurrently through the host-memory path (staging arenas, side streams, the chunked pipeline's helper thread)
+    and through the device path; every result must equal the one computed alone."""
+    import threading
+    from ocean_bgc_amd.modules import ColumnEngine
+    monkeypatch.setenv("OBGC_HOST_PIPELINE_MIN_MB", "0")     # the host path in chunks, with its download thread
+    nz = 60
+    jobs = [(3000, 11), (2500, 70001)]
+
+    def inputs(nc, col0):
+        syn = synth.generate(nc, nz, col0=col0)
+        return (synth.bgc_tracer_array(syn), syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"],
+                syn["kmax"], syn["fesed"], syn["dust"], syn["sw"], np.zeros((nc, nz)), np.zeros((nc, nz)))
+
+    def run(path, nc, col0, out, key, reps):
+        E = ColumnEngine(0, path=path)
+        args = inputs(nc, col0)
+        for _ in range(reps):
+            out[key] = E.BGC_SourceSink(*args)
+
+    for path in ("host", "device_colfast"):
+        alone, together = {}, {}
+        for i, (nc, col0) in enumerate(jobs):
+            run(path, nc, col0, alone, i, 1)
+        threads = [threading.Thread(target=run, args=(path, nc, col0, together, i, 3)) for i, (nc, col0) in enumerate(jobs)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for i in range(len(jobs)):
+            assert set(together) == set(alone)
+            a, b = alone[i], together[i]
+            assert np.array_equal(a["tend"], b["tend"]) and np.array_equal(a["ph_prev"], b["ph_prev"]), (path, i)
+            for grp in ("kc", "kca", "ca", "c"):
+                for nm in a[grp]:
+                    assert np.array_equal(a[grp][nm], b[grp][nm]), (path, i, grp, nm)
