@@ -32,6 +32,7 @@ struct obgc_handle {
   hipStream_t s_aux2 = nullptr;   // column integrals (diagnostics) run beside both
   hipStream_t s_up = nullptr, s_down = nullptr;   // host-memory path: uploads / downloads of column chunks (created on first use)
   int host_chunks = 4;    // OBGC_HOST_CHUNKS: column chunks of the pipelined host-memory path (0 or 1 = stage everything, then run)
+  int host_threads = 1;   // OBGC_HOST_THREADS=0: no helper thread (downloads in line, as when thread creation fails)
   size_t host_pipeline_min_bytes = (size_t)64 << 20;   // OBGC_HOST_PIPELINE_MIN_MB: smaller calls are staged in one piece
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
              ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_aux2_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
@@ -334,6 +335,7 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
   if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
   if (const char* e = std::getenv("OBGC_HOST_CHUNKS")) h->host_chunks = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_HOST_THREADS")) h->host_threads = std::atoi(e);
   if (const char* e = std::getenv("OBGC_HOST_PIPELINE_MIN_MB")) h->host_pipeline_min_bytes = (size_t)std::atoll(e) << 20;
   if (const char* e = std::getenv("OBGC_KFAST_TILE")) { const int t = std::atoi(e); if (t >= 64) h->kfast_tile = t; }
   obgc_bgc_params_init(&h->bgc, nullptr, 273.15);
@@ -639,29 +641,39 @@ int host_pipeline(obgc_handle* h, Stager& st, const GridView& v, const BgcKernel
   int ready = 0;            // chunks whose kernels (and ev_done) are enqueued
   bool stop = false;
   hipError_t down_err = hipSuccess;
-  std::thread downloader([&] {
-    hipError_t e = hipSetDevice(h->device);
-    for (int i = 0; i < nchunk && e == hipSuccess; ++i) {
-      {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return ready > i || stop; });
-        if (ready <= i) break;   // the producer gave up
-      }
-      const int c0 = i * chunk, c1 = (c0 + chunk < v.ncol) ? c0 + chunk : v.ncol;
-      e = hipStreamWaitEvent(h->s_down, ev_done[(size_t)i], 0);
-      for (size_t k = 0; k < st.items.size() && e == hipSuccess; ++k) {
-        const Stage& it = st.items[k];
-        if (!it.out || it.nplanes <= 0) continue;
-        for (int n = 0; n < it.nplanes && e == hipSuccess; ++n) {
-          size_t b, len;
-          chunk_range(it, v, n, c0, c1, b, len);
-          if (len) e = hipMemcpyAsync((char*)it.host + b, (char*)it.dev + b, len, hipMemcpyDeviceToHost, h->s_down);
-        }
+  auto download_chunk = [&](int i, hipStream_t stream) -> hipError_t {
+    const int c0 = i * chunk, c1 = (c0 + chunk < v.ncol) ? c0 + chunk : v.ncol;
+    hipError_t e = hipStreamWaitEvent(stream, ev_done[(size_t)i], 0);
+    for (size_t k = 0; k < st.items.size() && e == hipSuccess; ++k) {
+      const Stage& it = st.items[k];
+      if (!it.out || it.nplanes <= 0) continue;
+      for (int n = 0; n < it.nplanes && e == hipSuccess; ++n) {
+        size_t b, len;
+        chunk_range(it, v, n, c0, c1, b, len);
+        if (len) e = hipMemcpyAsync((char*)it.host + b, (char*)it.dev + b, len, hipMemcpyDeviceToHost, stream);
       }
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(h->s_down);
-    down_err = e;
-  });
+    return e;
+  };
+  std::thread downloader;
+  bool threaded = h->host_threads != 0;
+  try {
+    if (threaded) downloader = std::thread([&] {
+      hipError_t e = hipSetDevice(h->device);
+      for (int i = 0; i < nchunk && e == hipSuccess; ++i) {
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return ready > i || stop; });
+          if (ready <= i) break;   // the producer gave up
+        }
+        e = download_chunk(i, h->s_down);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(h->s_down);
+      down_err = e;
+    });
+  } catch (...) {
+    threaded = false;   // no second thread to be had: same chunks, downloads in line
+  }
 
   int rc = OBGC_OK;
   hipError_t e = hipSuccess;
@@ -683,6 +695,10 @@ int host_pipeline(obgc_handle* h, Stager& st, const GridView& v, const BgcKernel
     if (rc != OBGC_OK) break;
     e = hipEventRecord(ev_done[(size_t)i], h->s_main);
     if (e != hipSuccess) break;
+    if (!threaded) {
+      e = download_chunk(i, h->s_main);
+      continue;
+    }
     {
       std::lock_guard<std::mutex> lk(m);
       ready = i + 1;
@@ -694,7 +710,7 @@ int host_pipeline(obgc_handle* h, Stager& st, const GridView& v, const BgcKernel
     stop = true;
   }
   cv.notify_one();
-  downloader.join();
+  if (threaded) downloader.join();
   (void)hipStreamSynchronize(h->s_main);
   destroy_events();
   if (rc != OBGC_OK) return rc;

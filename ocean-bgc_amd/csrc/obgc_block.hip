@@ -25,7 +25,7 @@ struct obgc_block {
   int* m_kmax;
   // pipelined step: cell chunks, results of chunk i go down on s_down while chunk i+1 comes up on the engine's stream
   enum { kMaxChunks = 16 };
-  int chunks = 8, min_cells = 8192;
+  int chunks = 8, min_cells = 8192, threads = 1;   // OBGC_HOST_THREADS=0: downloads in line
   hipStream_t s_down = nullptr;
   hipEvent_t ev_done[kMaxChunks] = {};
 };
@@ -162,6 +162,7 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
   (void)hipMemsetAsync(b->gas, 0, NT * nc * d, st);
   if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(b->pool); delete b; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_BLOCK_CHUNKS")) b->chunks = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_HOST_THREADS")) b->threads = std::atoi(e);
   if (const char* e = std::getenv("OBGC_BLOCK_MIN_CELLS")) b->min_cells = std::atoi(e);
   if (b->chunks < 1) b->chunks = 1;
   if (b->chunks > obgc_block::kMaxChunks) b->chunks = obgc_block::kMaxChunks;
@@ -296,27 +297,37 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   hipError_t down_err = hipSuccess;
   int device = 0;
   (void)hipGetDevice(&device);
-  std::thread downloader([&] {
-    hipError_t e = hipSetDevice(device);
-    for (int i = 0; i < nchunk && e == hipSuccess; ++i) {
-      {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return ready > i || stop; });
-        if (ready <= i) break;
+  std::thread downloader;
+  bool threaded = b->threads != 0;
+  try {
+    if (threaded) downloader = std::thread([&] {
+      hipError_t e = hipSetDevice(device);
+      for (int i = 0; i < nchunk && e == hipSuccess; ++i) {
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return ready > i || stop; });
+          if (ready <= i) break;
+        }
+        const int c0 = i * chunk, c1 = (c0 + chunk < nc) ? c0 + chunk : nc;
+        e = hipStreamWaitEvent(b->s_down, b->ev_done[i], 0);
+        if (e == hipSuccess) e = block_download_range(b, a, c0, c1, b->s_down);
       }
-      const int c0 = i * chunk, c1 = (c0 + chunk < nc) ? c0 + chunk : nc;
-      e = hipStreamWaitEvent(b->s_down, b->ev_done[i], 0);
-      if (e == hipSuccess) e = block_download_range(b, a, c0, c1, b->s_down);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(b->s_down);
-    down_err = e;
-  });
+      if (e == hipSuccess) e = hipStreamSynchronize(b->s_down);
+      down_err = e;
+    });
+  } catch (...) {
+    threaded = false;   // no second thread to be had: same ranges, downloads in line
+  }
   int rc = OBGC_OK;
   for (int i = 0; i < nchunk && rc == OBGC_OK; ++i) {
     const int c0 = i * chunk, c1 = (c0 + chunk < nc) ? c0 + chunk : nc;
     rc = block_step_range(b, a, c0, c1);
     if (rc == OBGC_OK && hipEventRecord(b->ev_done[i], st) != hipSuccess) rc = OBGC_ERR_HIP;
     if (rc != OBGC_OK) break;
+    if (!threaded) {
+      if (block_download_range(b, a, c0, c1, st) != hipSuccess) rc = OBGC_ERR_HIP;
+      continue;
+    }
     {
       std::lock_guard<std::mutex> lk(m);
       ready = i + 1;
@@ -328,7 +339,7 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
     stop = true;
   }
   cv.notify_one();
-  downloader.join();
+  if (threaded) downloader.join();
   if (hipStreamSynchronize(st) != hipSuccess && rc == OBGC_OK) rc = OBGC_ERR_HIP;
   if (rc == OBGC_OK && down_err != hipSuccess) rc = OBGC_ERR_HIP;
   return rc;

@@ -201,7 +201,8 @@ def test_reference_layout_tiled_transposes(pkg, oracle, synth, monkeypatch):
     _assert(P.compare_bgc(a, oracle.bgc_source_sink(*args, z, z, diag_init=-7.0)), "tiled reference layout")
 
 
-def test_host_path_pipelined_in_column_chunks(pkg, synth, monkeypatch):
+@pytest.mark.parametrize("threads", ["1", "0"])
+def test_host_path_pipelined_in_column_chunks(pkg, synth, monkeypatch, threads):
     """Host-memory callers in the reference layout are served chunk by chunk (upload, kernels and download of
     different column chunks overlap).  Force five chunks with a short last one, plain and with padded leading
     dimensions, and require the bits of the one-piece path; the padding and the never-written members stay as they were."""
@@ -242,6 +243,7 @@ def test_host_path_pipelined_in_column_chunks(pkg, synth, monkeypatch):
     one = Engine(0)
     monkeypatch.setenv("OBGC_HOST_CHUNKS", "5")
     monkeypatch.setenv("OBGC_HOST_PIPELINE_MIN_MB", "0")
+    monkeypatch.setenv("OBGC_HOST_THREADS", threads)          # "0": the fallback without a helper thread
     piped = Engine(0)
     for ld, extra in ((nz, 0), (nz + 3, 2)):
         a, av = run(one, ld, extra)

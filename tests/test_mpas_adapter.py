@@ -200,8 +200,8 @@ def block_step(L, eng, blk, m, nc, nz, tend, accumulate):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, oracle, pkg, monkeypatch, chunks):
+@pytest.mark.parametrize("chunks,threads", [(1, "1"), (3, "1"), (3, "0")])
+def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, oracle, pkg, monkeypatch, chunks, threads):
     """The device-resident block (obgc_block_*): same bits as the Fortran adapter through the host path, parity bars
     against the numpy + oracle restatement, and the accumulate switch.  chunks = 3: the pipelined step (cell ranges
     of 256, 256 and 128 cells going up, through the kernels and down concurrently)."""
@@ -210,6 +210,7 @@ def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, 
         pytest.fail("needs a GPU")
     monkeypatch.setenv("OBGC_BLOCK_CHUNKS", str(chunks))
     monkeypatch.setenv("OBGC_BLOCK_MIN_CELLS", "0")
+    monkeypatch.setenv("OBGC_HOST_THREADS", threads)
     if not os.path.exists(EXE_GPU):
         subprocess.check_call(["make", "-s", "-C", FDIR])
     from ocean_bgc_amd import _lib as L
