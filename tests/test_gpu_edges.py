@@ -213,3 +213,27 @@ def test_two_host_threads_with_their_own_handles(pkg, synth, monkeypatch):
             for grp in ("kc", "kca", "ca", "c"):
                 for nm in a[grp]:
                     assert np.array_equal(a[grp][nm], b[grp][nm]), (path, i, grp, nm)
+
+
+@pytest.mark.gpu
+def test_scheduling_variants_give_the_same_bits(pkg, synth, monkeypatch):
+    """OBGC_SCHED only moves the carbonate solve in time (beside the light kernels, after the cell kernel, or inside the
+    cell kernel's wavefronts -- the default for large batches with diagnostics): every variant runs the same
+    carbonate_cell code, so the results must be bit-identical, with and without diagnostics."""
+    from ocean_bgc_amd.modules import ColumnEngine
+    nc, nz = 3000, 60
+    syn = synth.generate(nc, nz, col0=424242)
+    args = (synth.bgc_tracer_array(syn), syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
+            syn["fesed"], syn["dust"], syn["sw"], np.zeros((nc, nz)), np.zeros((nc, nz)))
+    out = {}
+    for sched in ("1", "0", "2"):
+        monkeypatch.setenv("OBGC_SCHED", sched)
+        E = ColumnEngine(0, path="device_colfast")
+        out[sched] = (E.BGC_SourceSink(*args, diagnostics=True), E.BGC_SourceSink(*args, diagnostics=False))
+    for sched in ("0", "2"):
+        for a, b in zip(out["1"], out[sched]):
+            assert np.array_equal(a["tend"], b["tend"]) and np.array_equal(a["ph_prev"], b["ph_prev"]), sched
+            assert np.array_equal(a["ph_prev_alt"], b["ph_prev_alt"]), sched
+            for grp in ("kc", "kca", "ca", "c"):
+                for nm in a[grp]:
+                    assert np.array_equal(a[grp][nm], b[grp][nm]), (sched, grp, nm)
