@@ -42,7 +42,7 @@ struct obgc_handle {
   int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides
   int kfast_hybrid = 1;   // OBGC_KFAST_HYBRID=0: transpose every plane (the first implementation) instead of only the column kernels' planes
   int sched = -1;  // OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel, 2 carbonate inside the cell kernel's
-                   // wavefronts, -1 (default) = 1, or 2 for batches of more than 10 M cells with diagnostics (see bgc_launch)
+                   // wavefronts, -1 (default) = 1, or for batches of more than 10 M cells 2 with diagnostics and 0 without (see bgc_launch)
   obgc_bgc_params bgc;
   obgc_dms_params dms;
   obgc_macros_params macros;
@@ -478,7 +478,9 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   // Large batches with diagnostics: the sweep (one wave per SIMD) is the longest kernel of the last phase and a
   // carbonate kernel beside it only slows it down (13.5 ms against 6.9 ms alone at 1 M columns), so the carbonate system
   // is solved inside the cell kernel's wavefronts instead: -4 % at 200 k - 1 M columns, +3 % at 100 k (measured).
-  const int sched = h->sched >= 0 ? h->sched : ((K.have_diag && (long long)K.g.nlev * K.g.ncol > 10000000LL) ? 2 : 1);
+  // Without diagnostics the large batches do best with the carbonate kernel started first (-4 % at 1 M columns, nothing at 100 k).
+  const bool large = (long long)K.g.nlev * K.g.ncol > 10000000LL;
+  const int sched = h->sched >= 0 ? h->sched : (large ? (K.have_diag ? 2 : 0) : 1);
   HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
   launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1, sched == 2);
   h->cell_valid = true;
