@@ -128,6 +128,30 @@ def test_cfg3_1M_x_60_tendencies_only(gpu):
     assert torch.equal(s["tend"], b["tend"][:, :, w0:w0 + wn]) and torch.equal(s["ph"], b["ph"][:, :, w0:w0 + wn])
 
 
+def test_large_batch_with_diagnostics_takes_the_fused_schedule(gpu):
+    """Above 10 M cells with diagnostics the library solves the carbonate system inside the cell kernel's wavefronts
+    (DESIGN.md section 4): 400 000 columns x 60 with every diagnostic, against a 640-column window computed on its own
+    (separate carbonate kernel) -- every output bit-identical, conservation to round-off, zero fill below the floor."""
+    torch, L, eng = gpu
+    nz, nc = 60, 400_000
+    b = make_batch(torch, L, eng, nz, nc, 0, diag=True)
+    run(L, eng, b)
+    k = torch.arange(nz, device="cuda")[:, None]
+    below = k >= b["kmax"][None, :]
+    assert torch.isfinite(b["tend"]).all() and (b["tend"][:, below] == 0).all()
+    scale = float(b["diag"]["photoC_TOT_zint"].abs().max())
+    for nm, fac in (("Jint_Ctot", 1.0), ("Jint_Ntot", 0.137), ("Jint_Ptot", 0.00855), ("Jint_Sitot", 0.137)):
+        assert float(b["diag"][nm].abs().max()) <= 1e-10 * scale * fac, nm
+    w0, wn = 333_312, 640
+    s = make_batch(torch, L, eng, nz, wn, w0, diag=True)
+    run(L, eng, s)
+    assert torch.equal(s["tend"], b["tend"][:, :, w0:w0 + wn]) and torch.equal(s["ph"], b["ph"][:, :, w0:w0 + wn])
+    for nm, v in s["diag"].items():
+        assert torch.equal(v, b["diag"][nm][..., w0:w0 + wn]), nm
+    del b, s
+    torch.cuda.empty_cache()
+
+
 def test_reference_layout_equals_native_layout_at_scale(gpu, monkeypatch):
     """The reference (level-fastest) layout on the device -- cell-parallel kernels on the caller's arrays, LDS transposes
     for the column kernels' planes, several column tiles -- must leave exactly the bits of the native layout in every
