@@ -153,6 +153,28 @@ def test_permuted_slots_and_parameters(pkg, synth):
     _assert(P.compare_bgc(E.BGC_SourceSink(*args, z, z), O.bgc_source_sink(*args, z, z)), "permuted")
 
 
+@pytest.mark.parametrize("variant", ["temperature functions swapped", "one grazee class", "all grazee classes distinct",
+                                     "two N fixers, no calcifier"])
+def test_autotroph_flag_variants(pkg, synth, variant):
+    """The integer side of the autotroph table (tests/test_oracle_vs_reference.py pins the oracle on the same variants):
+    nothing in the kernels may assume which group fixes N2, calcifies, shares a grazee class or follows which
+    temperature function."""
+    from ocean_bgc_amd.modules import ColumnEngine
+    from oracle import orabind
+    from test_oracle_vs_reference import FLAG_VARIANTS, with_flags
+    E = ColumnEngine(0, path="device_colfast")
+    O = orabind.Oracle()
+    p = with_flags(O.bgc_get_params(), FLAG_VARIANTS[variant])
+    O.bgc_set_params(p)
+    E.bgc_set_params(p)
+    nc, nz = 1500, 60
+    syn = synth.generate(nc, nz, col0=4242)
+    args = (synth.bgc_tracer_array(syn), syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
+            syn["fesed"], syn["dust"], syn["sw"])
+    z = np.zeros((nc, nz))
+    _assert(P.compare_bgc(E.BGC_SourceSink(*args, z, z), O.bgc_source_sink(*args, z, z)), variant)
+
+
 def test_device_generator_is_bit_identical_to_numpy(pkg, synth):
     import torch
     from ocean_bgc_amd.engine import Engine

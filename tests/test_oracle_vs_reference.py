@@ -78,6 +78,43 @@ def test_bgc_permuted_indices_and_parameters(synth):
     refbind.Ref()
 
 
+FLAG_VARIANTS = {
+    "temperature functions swapped": {"temp_function": [2, 1, 2, 1]},
+    "one grazee class": {"grazee_ind": [1, 1, 1, 1]},
+    "all grazee classes distinct": {"grazee_ind": [1, 2, 3, 4]},
+    "two N fixers, no calcifier": {"Nfixer": [0, 1, 1, 0], "imp_calcifier": [0, 0, 0, 0]},
+}
+
+
+def with_flags(p0, changes):
+    p = {k: np.array(v, copy=True) for k, v in p0.items()}
+    for name, vals in changes.items():
+        p["aint"][:, F.AUTOTROPH_INTS.index(name)] = vals
+    return p
+
+
+@pytest.mark.parametrize("variant", sorted(FLAG_VARIANTS))
+def test_bgc_autotroph_flag_variants(synth, variant):
+    """A host may re-configure the autotroph table (which group fixes N2, calcifies, which share a grazee class, which
+    temperature function they follow): the restatement must follow the reference bit for bit through those branches too."""
+    from oracle import orabind, refbind
+    if not refbind.available():
+        pytest.skip("reference library not built")
+    R, O = refbind.Ref(), orabind.Oracle()
+    p = with_flags(R.bgc_get_params(), FLAG_VARIANTS[variant])
+    R.bgc_set_params(p)
+    O.bgc_set_params(p)
+    nc, nz = 300, 60
+    syn = synth.generate(nc, nz, col0=4242)
+    args = bgc_args(synth, syn)
+    z = np.zeros((nc, nz))
+    a, b = R.bgc_source_sink(*args, z, z), O.bgc_source_sink(*args, z, z)
+    compare_bgc(a, b)
+    default = orabind.Oracle().bgc_source_sink(*args, z, z)
+    assert not np.array_equal(default["tend"], b["tend"])        # the variant really takes another path
+    refbind.Ref()                                               # restore the reference's module variables
+
+
 def test_surface_dms_macros(ref, oracle, synth):
     nc, nz = 3000, 60
     syn = synth.generate(nc, nz, col0=777)
