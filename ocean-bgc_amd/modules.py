@@ -55,6 +55,17 @@ class ColumnEngine:
     def macros_get_parms(self):
         return np.array([getattr(self.eng.macros, n) for n in L.MACROS_PARMS])
 
+    def dms_set_parms(self, p):
+        """The host changing DMS_parms module variables between calls (DMS_parms.F90:203-241 sets the defaults)."""
+        for n, v in zip(L.DMS_PARMS, p):
+            setattr(self.eng.dms, n, float(v))
+        self.eng.push_params()
+
+    def macros_set_parms(self, p):
+        for n, v in zip(L.MACROS_PARMS, p):
+            setattr(self.eng.macros, n, float(v))
+        self.eng.push_params()
+
     def names(self, module):
         n = {0: 30, 1: 14, 2: 8}[module]
         return [tuple(self.eng.lib.obgc_tracer_name(module, i, w).decode() for w in range(3)) for i in range(1, n + 1)]

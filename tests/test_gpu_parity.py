@@ -175,6 +175,34 @@ def test_autotroph_flag_variants(pkg, synth, variant):
     _assert(P.compare_bgc(E.BGC_SourceSink(*args, z, z), O.bgc_source_sink(*args, z, z)), variant)
 
 
+@pytest.mark.parametrize("path", PATHS)
+def test_dms_macros_permuted_slots_and_parameters(pkg, synth, path):
+    """DMS / MACROS with their tracer slots shuffled and every parameter off its default (the oracle is pinned on the
+    same case in tests/test_oracle_vs_reference.py)."""
+    from ocean_bgc_amd.modules import ColumnEngine
+    from oracle import orabind
+    from test_oracle_vs_reference import dms_macros_case
+    rng = np.random.RandomState(23)
+    dperm, mperm, syn, dtr, mtr = dms_macros_case(synth, rng)
+    E = ColumnEngine(0, dms_indices=dperm, macros_indices=mperm, path=path)
+    O = orabind.Oracle(dms_indices=dperm, macros_indices=mperm)
+    dp = O.dms_get_parms() * (1.0 + 0.1 * rng.rand(len(F.DMS_PARMS)))
+    mp = O.macros_get_parms() * (1.0 + 0.1 * rng.rand(len(F.MACROS_PARMS)))
+    O.dms_set_parms(dp); E.dms_set_parms(dp)
+    O.macros_set_parms(mp); E.macros_set_parms(mp)
+    f = syn["forcing"]
+    rep = P.Report()
+    P.compare_simple(E.DMS_SourceSink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"], diag_init=-2.0),
+                     O.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"], diag_init=-2.0), "dms", rep)
+    P.compare_simple(E.MACROS_SourceSink(mtr, syn["kmax"], diag_init=-2.0), O.macros_source_sink(mtr, syn["kmax"], diag_init=-2.0),
+                     "macros", rep)
+    a, b = E.DMS_SurfaceFluxes(dtr, f, diag_init=-2.0), O.dms_surface_fluxes(dtr, f, diag_init=-2.0)
+    written = [int(dperm[0]) - 1, int(dperm[1]) - 1]                      # the dms / dmsp rows, wherever the host put them
+    rep.note("diag", "dms.netFlux", P.e_norm(a["netFlux"][written], b["netFlux"][written]), P.TOL_DIAG)
+    assert np.array_equal(a["netFlux"], b["netFlux"]) or (np.delete(a["netFlux"], written, axis=0) == -2.0).all()
+    _assert(rep, "dms/macros permuted " + path)
+
+
 def test_device_generator_is_bit_identical_to_numpy(pkg, synth):
     import torch
     from ocean_bgc_amd.engine import Engine

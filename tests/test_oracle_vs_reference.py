@@ -153,3 +153,44 @@ def test_init_names_and_units(ref):
     assert names[8][2] == "meq/m^3" and names[17][2] == "mg/m^3"      # BGC_mod.F90:323-328
     assert names[23][0] == "diatSi" and names[19][0] == "spCaCO3"     # BGC_mod.F90:303-320
     assert ref.dms_names()[1][0] == "DMSP" and ref.macros_names()[2][0] == "LIP"
+
+
+def dms_macros_case(synth, rng):
+    """permuted DMS / MACROS tracer slots, parameters off their defaults by up to 10 %"""
+    dperm, mperm = rng.permutation(14) + 1, rng.permutation(8) + 1
+    nc, nz = 700, 60
+    syn = synth.generate(nc, nz, col0=31337)
+    dtr = synth.dms_tracer_array(syn, {nm: int(dperm[i]) for i, nm in enumerate(F.DMS_TRACERS)})
+    mtr = synth.macros_tracer_array(syn, {nm: int(mperm[i]) for i, nm in enumerate(F.MACROS_TRACERS)})
+    return dperm, mperm, syn, dtr, mtr
+
+
+def test_dms_macros_permuted_slots_and_parameters(synth):
+    from oracle import orabind, refbind
+    if not refbind.available():
+        pytest.skip("reference library not built")
+    rng = np.random.RandomState(23)
+    dperm, mperm, syn, dtr, mtr = dms_macros_case(synth, rng)
+    R = refbind.Ref(dms_indices=dperm, macros_indices=mperm)
+    O = orabind.Oracle(dms_indices=dperm, macros_indices=mperm)
+    dp = R.dms_get_parms() * (1.0 + 0.1 * rng.rand(len(F.DMS_PARMS)))
+    mp = R.macros_get_parms() * (1.0 + 0.1 * rng.rand(len(F.MACROS_PARMS)))
+    R.dms_set_parms(dp); O.dms_set_parms(dp)
+    R.macros_set_parms(mp); O.macros_set_parms(mp)
+    f = syn["forcing"]
+    d1 = R.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"], diag_init=-2.0)
+    d2 = O.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"], diag_init=-2.0)
+    assert_same("dms.tend", d2["tend"], d1["tend"])
+    for nm in d1["kc"]:
+        assert_same("dms." + nm, d2["kc"][nm], d1["kc"][nm])
+    e1, e2 = R.dms_surface_fluxes(dtr, f, diag_init=-2.0), O.dms_surface_fluxes(dtr, f, diag_init=-2.0)
+    assert_same("dms.net", e2["netFlux"], e1["netFlux"])
+    m1, m2 = R.macros_source_sink(mtr, syn["kmax"], diag_init=-2.0), O.macros_source_sink(mtr, syn["kmax"], diag_init=-2.0)
+    assert_same("macros.tend", m2["tend"], m1["tend"])
+    for nm in m1["kc"]:
+        assert_same("macros." + nm, m2["kc"][nm], m1["kc"][nm])
+    default = orabind.Oracle(dms_indices=dperm, macros_indices=mperm)
+    assert not np.array_equal(default.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"])["tend"], d2["tend"])
+    R2 = refbind.Ref()                                          # restore the reference's module variables ...
+    R2.dms_set_parms(orabind.Oracle().dms_get_parms())          # ... including the parameters *_parms_init does not reset
+    R2.macros_set_parms(orabind.Oracle().macros_get_parms())
