@@ -237,3 +237,59 @@ def test_scheduling_variants_give_the_same_bits(pkg, synth, monkeypatch):
             for grp in ("kc", "kca", "ca", "c"):
                 for nm in a[grp]:
                     assert np.array_equal(a[grp][nm], b[grp][nm]), (sched, grp, nm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["colfast", "kfast"])
+def test_any_selection_of_diagnostics(pkg, synth, layout):
+    """NULL members of obgc_bgc_diag are simply not written (include/obgc.h).  Random selections -- including column
+    integrals without the profiles they integrate, and saturation horizons without the CO3 fields, which the library
+    then keeps in scratch -- must give, member by member, the bits of the call that asks for everything."""
+    import torch
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    eng = Engine(0)
+    nc, nz = 1100, 60
+    syn = synth.generate(nc, nz, col0=2718)
+    dev = torch.device("cuda:0")
+    kfast = layout == "kfast"
+    lay = L.OBGC_LAYOUT_KFAST if kfast else L.OBGC_LAYOUT_COLFAST
+
+    def up(x):        # reference order [.., c, k]
+        t = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        return t if kfast else t.transpose(-1, -2).contiguous()
+
+    tr = up(synth.bgc_tracer_array(syn))
+    kc = {k: up(syn[k]) for k in ("temp", "salt", "zmid", "dz", "zbot", "fesed")}
+    cc = {k: torch.from_numpy(np.ascontiguousarray(syn[k])).to(dev) for k in ("lat", "dust", "sw")}
+    kmax = torch.from_numpy(syn["kmax"].astype(np.int32)).to(dev)
+    shape_kc = (nc, nz) if kfast else (nz, nc)
+    names = L.BGC_DIAG_KC + L.BGC_DIAG_KCA + L.BGC_DIAG_CA + L.BGC_DIAG_C
+
+    def run(selected):
+        f64 = dict(dtype=torch.float64, device=dev)
+        d = {}
+        for nm in selected:
+            if nm in L.BGC_DIAG_KC: d[nm] = torch.full(shape_kc, -7.0, **f64)
+            elif nm in L.BGC_DIAG_KCA: d[nm] = torch.full((4,) + shape_kc, -7.0, **f64)
+            elif nm in L.BGC_DIAG_CA: d[nm] = torch.full((4, nc), -7.0, **f64)
+            else: d[nm] = torch.full((nc,), -7.0, **f64)
+        tend = torch.full((30,) + shape_kc, -7.0, **f64)
+        ph = torch.zeros((2,) + shape_kc, **f64)
+        torch.cuda.synchronize()
+        eng.bgc_source_sink(nz, nc, lay, tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"], cc["lat"], kmax, kc["fesed"],
+                            cc["dust"], cc["sw"], tend, ph[0], ph[1], d, True)
+        out = {nm: v.cpu().numpy() for nm, v in d.items()}
+        out["tend"], out["ph"] = tend.cpu().numpy(), ph.cpu().numpy()
+        return out
+
+    full = run(names)
+    rng = np.random.default_rng(17)
+    picks = [["photoC_zint", "photoC_NO3_zint", "CaCO3_form_zint", "photoC_TOT_zint", "zsatcalc", "zsatarag", "Jint_Ctot"],
+             ["zsatarag", "CO3"], ["POC_FLUX_IN", "O2_ZMIN", "Chl100m" if "Chl100m" in names else "O2_ZMIN_DEPTH"]]
+    picks += [list(rng.choice(names, size=n, replace=False)) for n in (1, 5, 25, 70)]
+    for sel in picks:
+        got = run(sel)
+        assert np.array_equal(got["tend"], full["tend"]) and np.array_equal(got["ph"], full["ph"]), sel
+        for nm in sel:
+            assert np.array_equal(got[nm], full[nm]), (layout, nm, sel)
