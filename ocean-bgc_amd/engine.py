@@ -141,9 +141,17 @@ class Engine:
         return L.OBGC_MEM_DEVICE if dev else L.OBGC_MEM_HOST
 
     # ---- compute entry points -------------------------------------------------------------
-    def bgc_source_sink(self, nlev, ncol, layout, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesedflux,
-                        dust_flux_in, sw_flux, tend, ph_prev, ph_prev_alt, diag=None, alt_co2_use_eco=True, ld=0,
-                        plane=0, ldc=0):
+    def bgc_source_sink(self, *args, **kw):
+        self.bgc_source_sink_run(self.bgc_source_sink_prepare(*args, **kw))
+
+    def bgc_source_sink_run(self, prepared):
+        """One obgc_bgc_source_sink call on an argument block built by bgc_source_sink_prepare: what a compiled host does
+        per step (the arrays, hence the block, do not change between steps)."""
+        self._check(self.lib.obgc_bgc_source_sink(self.h, prepared[0]), "obgc_bgc_source_sink")
+
+    def bgc_source_sink_prepare(self, nlev, ncol, layout, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesedflux,
+                                dust_flux_in, sw_flux, tend, ph_prev, ph_prev_alt, diag=None, alt_co2_use_eco=True, ld=0,
+                                plane=0, ldc=0):
         ms = self._memspace(tracers)
         a = L.BgcSourceSinkArgs()
         a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
@@ -158,7 +166,7 @@ class Engine:
             self._fill(d, L.BGC_DIAG_KC + L.BGC_DIAG_KCA + L.BGC_DIAG_CA + L.BGC_DIAG_C, diag, ms)
             a.diag = C.pointer(d)
         a.alt_co2_use_eco = 1 if alt_co2_use_eco else 0
-        self._check(self.lib.obgc_bgc_source_sink(self.h, C.byref(a)), "obgc_bgc_source_sink")
+        return (C.byref(a), a, d)          # byref object + what it points to (kept alive by the tuple)
 
     def bgc_surface_fluxes(self, nlev, ncol, layout, tracers, forcing, depositionFlux, riverFlux, gasFlux, seaIceFlux,
                            netFlux, diag=None, lcalc_O2_gas_flux=True, lcalc_CO2_gas_flux=True, ld=0, plane=0, ldc=0):
