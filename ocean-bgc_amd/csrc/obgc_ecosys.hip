@@ -54,7 +54,10 @@ constexpr double QN = 0.137, QP_ZOO_POM = 0.00855, QFE_ZOO = 3.0e-6, GQSI_0 = 0.
 constexpr double THRES_Z1 = 100.0e2, THRES_Z2 = 150.0e2, LOSS_THRES_ZOO = 0.005, CACO3_TEMP_THRES1 = 6.0,
                  CACO3_TEMP_THRES2 = -2.0, CACO3_SP_THRES = 4.0;        // 435-441
 constexpr int TFNC_Q10 = 1, TFNC_QUASI_MMRT = 2;        // 447-449
-constexpr double F_QSW_PAR = 0.45, TREF = 30.0, Q_10 = 1.5;             // 454-463
+constexpr double F_QSW_PAR = 0.45, TREF = 30.0;   // 454-463 (Q_10 = 1.5 enters through LN_Q_10 below)
+// Q_10**x and 0.99**x are evaluated as exp(x ln b), x**1.5 as x sqrt(x): the device pow() costs ~200 fp64 instructions
+// (it cannot know its base is a constant), exp ~40, sqrt ~20.  Same function, <= 2 ulp from pow.
+constexpr double LN_Q_10 = 0.4054651081081644, LN_0_99 = -0.01005033585350145;
 constexpr double DOC_REMINR = (1.0 / 250.0) * DPS, DON_REMINR = (1.0 / 160.0) * DPS, DOFE_REMINR = (1.0 / 160.0) * DPS,
                  DOP_REMINR = (1.0 / 160.0) * DPS, DONR_REMINR = (1.0 / (365.0 * 2.5)) * DPS,
                  DOPR_REMINR = (1.0 / (365.0 * 2.5)) * DPS, DONREFRACT = 0.08, DOPREFRACT = 0.03;   // 469-477
@@ -319,7 +322,7 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   }
 
   // temperature response and loss thresholds (1041-1055)
-  const double Tfunc = pow(Q_10, ((T + T0K) - (TREF + T0K)) / 10.0);
+  const double Tfunc = exp((((T + T0K) - (TREF + T0K)) / 10.0) * LN_Q_10);   // Q_10 ** ((T + T0) - (Tref + T0)) / 10)
   double f_loss_thres;
   if (zc > THRES_Z1) f_loss_thres = (zc < THRES_Z2) ? (THRES_Z2 - zc) / (THRES_Z2 - THRES_Z1) : 0.0;
   else f_loss_thres = 1.0;
@@ -363,7 +366,7 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   const double f_zoo_detr = w1 / w2;
   if (DIAG) { ST_KC(AOU, aou); ST_KC(PAR_avg, PAR_avg); }   // first stores: every load has been issued by now
   const double Zprime = dmax(zooC - f_loss_thres * LOSS_THRES_ZOO, 0.0);
-  const double zoo_loss = (P.parm_z_mort2_0 * pow(Zprime, 1.5) + P.parm_z_mort_0 * Zprime) * Tfunc;
+  const double zoo_loss = (P.parm_z_mort2_0 * (Zprime * sqrt(Zprime)) + P.parm_z_mort_0 * Zprime) * Tfunc;   // Zprime ** 1.5
   const double zoo_loss_doc = (1.0 - P.parm_labile_ratio) * (1.0 - f_zoo_detr) * zoo_loss;
   const double zoo_loss_dic = P.parm_labile_ratio * (1.0 - f_zoo_detr) * zoo_loss;
 
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
       else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
       else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
     }
-    const double TfuncS = pow(1.5, ((cur.T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC)) / 10.0);
+    const double TfuncS = exp((((cur.T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC)) / 10.0) * LN_Q_10);   // 1.5 ** (...)
     double poc_diss = P.parm_POC_diss;
     if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
     else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
       if (flux > 0.0) {
         flux_alt = flux * 0.01 * SPD;
         sedPOC = flux * dmin(0.8, P.parm_POMbury * (0.013 + 0.53 * flux_alt * flux_alt / ((7.0 + flux_alt) * (7.0 + flux_alt))));
-        SED_DENITRIF = dzr * flux * (0.06 + 0.19 * pow(0.99, (O2 - NO3)));
+        SED_DENITRIF = dzr * flux * (0.06 + 0.19 * exp((O2 - NO3) * LN_0_99));   // 0.99 ** (O2 - NO3)
         if (NO3 < 5.0) SED_DENITRIF = 0.0;
         flux_alt = flux * 1.0e-6 * SPD * 365.0;
         OTHER_REMIN = dzr * dmin(dmin(0.1 + flux_alt, 0.5) * (flux - sedPOC), (flux - sedPOC - (SED_DENITRIF * dz * DENITRIF_C_N)));

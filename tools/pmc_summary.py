@@ -37,7 +37,9 @@ def short(name):
 
 
 def main():
-    out = {"fetch_correction": FETCH_CORRECTION, "unit": "bytes per launch", "runs": {}}
+    import os
+    rev = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ocean-bgc_amd", "KERNEL_REV")).read().strip()
+    out = {"kernel_rev": rev, "fetch_correction": FETCH_CORRECTION, "unit": "bytes per launch", "runs": {}}
     for spec in sys.argv[2:]:
         tag, dirs = spec.split("=")
         fd, wd = dirs.split(",")

@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_G
 done
 python3 - <<'PY'
 import csv, glob, collections, json
-out = {"unit": "fraction of the fp64 vector issue slots of 1024 SIMDs (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (GRBM_GUI_ACTIVE/8 x 1024))", "runs": {}}
+out = {"kernel_rev": open('ocean-bgc_amd/KERNEL_REV').read().strip(), "unit": "fraction of the fp64 vector issue slots of 1024 SIMDs (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (GRBM_GUI_ACTIVE/8 x 1024))", "runs": {}}
 for mode in ("full", "none"):
     f = glob.glob('gpurun_out/valu/%s/*/*_counter_collection.csv' % mode)[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
