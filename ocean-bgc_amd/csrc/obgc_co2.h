@@ -28,10 +28,23 @@ __device__ __forceinline__ double press_bar_of(double depth) {
   return 0.059808 * (exp(-0.025 * depth) - 1.0) + 0.100766 * depth + 2.28405e-7 * (depth * depth);
 }
 
-__device__ __forceinline__ double millero_kfac(double deltaV, double Kappa, double press_bar, double invRtk) {
-  double lnKfac = (-deltaV + 0.5 * Kappa * press_bar) * press_bar * invRtk;
-  return exp(lnKfac);
+__device__ __forceinline__ double millero_lnfac(double deltaV, double Kappa, double press_bar, double invRtk) {
+  return (-deltaV + 0.5 * Kappa * press_bar) * press_bar * invRtk;
 }
+__device__ __forceinline__ double millero_kfac(double deltaV, double Kappa, double press_bar, double invRtk) {
+  return exp(millero_lnfac(deltaV, Kappa, press_bar, invRtk));
+}
+
+// K(T,S) exp(lnKfac) -- the reference's two exponentials and a product (co2calc.F90:480-490 and alike) -- is evaluated as
+// ONE exponential of the summed exponents below the surface level: nine exp (~40 fp64 instructions each) less per
+// interior cell of a kernel whose instruction count is its run time.  |ln K| < 60 and |lnKfac| < 1, so the sum carries
+// an absolute rounding error of <= 4e-15, i.e. K moves by <= 4e-15 relative (pH by 2e-15).  At the surface level the
+// added exponent is an exact 0 and nothing changes.  -DOBGC_PRESSURE_FACTOR_SEPARATE restores the two-exponential form.
+#ifdef OBGC_PRESSURE_FACTOR_SEPARATE
+#define OBGC_K_AT_PRESSURE(arg, deep, dV, kap, pb, irt) (exp(arg) * ((deep) ? millero_kfac(dV, kap, pb, irt) : 1.0))
+#else
+#define OBGC_K_AT_PRESSURE(arg, deep, dV, kap, pb, irt) exp((arg) + ((deep) ? millero_lnfac(dV, kap, pb, irt) : 0.0))
+#endif
 
 // deep = (level index > 1): apply the pressure factors.  WANT_GAS also returns the
 // Weiss-Price fugacity factor ff (surface CO2 flux only; interior cells never use k0/ff).
@@ -74,46 +87,35 @@ __device__ __forceinline__ void comp_co3_coeffs(bool deep, double depth, double 
   arg = (-8966.90 - 2890.53 * sqrts - 77.942 * salt_lim + 1.728 * salt_lim * sqrts - 0.0996 * s2) * invtk +
         (148.0248 + 137.1942 * sqrts + 1.62142 * salt_lim) + (-24.4344 - 25.085 * sqrts - 0.2474 * salt_lim) * dlogtk +
         0.053105 * sqrts * tk;
-  c.kb = exp(arg);
+  c.kb = OBGC_K_AT_PRESSURE(arg, deep, bdV, -2.84 * p001, press_bar, invRtk);
   // k1p (560-580)
   arg = -4576.752 * invtk + 115.525 - 18.453 * dlogtk + (-106.736 * invtk + 0.69171) * sqrts +
         (-0.65643 * invtk - 0.01844) * salt_lim;
-  c.k1p = exp(arg);
+  c.k1p = OBGC_K_AT_PRESSURE(arg, deep, -14.51 + (0.1211 - 0.000321 * temp) * temp, (-2.67 + 0.0427 * temp) * p001, press_bar, invRtk);
   // k2p (589-609)
   arg = -8814.715 * invtk + 172.0883 - 27.927 * dlogtk + (-160.340 * invtk + 1.3566) * sqrts +
         (0.37335 * invtk - 0.05778) * salt_lim;
-  c.k2p = exp(arg);
+  c.k2p = OBGC_K_AT_PRESSURE(arg, deep, -23.12 + (0.1758 - 0.002647 * temp) * temp, (-5.15 + 0.09 * temp) * p001, press_bar, invRtk);
   // k3p (618-637)
   arg = -3070.75 * invtk - 18.141 + (17.27039 * invtk + 2.81197) * sqrts + (-44.99486 * invtk - 0.09984) * salt_lim;
-  c.k3p = exp(arg);
+  c.k3p = OBGC_K_AT_PRESSURE(arg, deep, -26.57 + (0.202 - 0.003042 * temp) * temp, (-4.08 + 0.0714 * temp) * p001, press_bar, invRtk);
   // ksi (647-669)
   arg = -8904.2 * invtk + 117.385 - 19.334 * dlogtk + (-458.79 * invtk + 3.5913) * sqrtis +
         (188.74 * invtk - 1.5998) * is + (-12.1652 * invtk + 0.07871) * is2 + log_1_m_1p005em3_s;
-  c.ksi = exp(arg);
+  c.ksi = OBGC_K_AT_PRESSURE(arg, deep, bdV, -2.84 * p001, press_bar, invRtk);
   // kw (681-700)
   arg = -13847.26 * invtk + 148.9652 - 23.6521 * dlogtk + (118.67 * invtk - 5.977 + 1.0495 * dlogtk) * sqrts -
         0.01615 * salt_lim;
-  c.kw = exp(arg);
+  c.kw = OBGC_K_AT_PRESSURE(arg, deep, -20.02 + (0.1119 - 0.001409 * temp) * temp, (-5.13 + 0.0794 * temp) * p001, press_bar, invRtk);
   // ks (709-731)
   arg = -4276.1 * invtk + 141.328 - 23.093 * dlogtk + (-13856.0 * invtk + 324.57 - 47.986 * dlogtk) * sqrtis +
         (35474.0 * invtk - 771.54 + 114.723 * dlogtk) * is - 2698.0 * invtk * is * sqrtis + 1776.0 * invtk * is2 +
         log_1_m_1p005em3_s;
-  c.ks = exp(arg);
-  if (deep) {
-    c.kb = c.kb * millero_kfac(bdV, -2.84 * p001, press_bar, invRtk);
-    c.k1p = c.k1p * millero_kfac(-14.51 + (0.1211 - 0.000321 * temp) * temp, (-2.67 + 0.0427 * temp) * p001, press_bar, invRtk);
-    c.k2p = c.k2p * millero_kfac(-23.12 + (0.1758 - 0.002647 * temp) * temp, (-5.15 + 0.09 * temp) * p001, press_bar, invRtk);
-    c.k3p = c.k3p * millero_kfac(-26.57 + (0.202 - 0.003042 * temp) * temp, (-4.08 + 0.0714 * temp) * p001, press_bar, invRtk);
-    c.ksi = c.ksi * millero_kfac(bdV, -2.84 * p001, press_bar, invRtk);
-    c.kw = c.kw * millero_kfac(-20.02 + (0.1119 - 0.001409 * temp) * temp, (-5.13 + 0.0794 * temp) * p001, press_bar, invRtk);
-    c.ks = c.ks * millero_kfac(-18.03 + (0.0466 + 0.000316 * temp) * temp, (-4.53 + 0.09 * temp) * p001, press_bar, invRtk);
-  }
+  c.ks = OBGC_K_AT_PRESSURE(arg, deep, -18.03 + (0.0466 + 0.000316 * temp) * temp, (-4.53 + 0.09 * temp) * p001, press_bar, invRtk);
   // kf needs the (corrected) ks (740-764)
   const double log_1_p_tot_sulfate_div_ks = log(1.0 + (0.1400 / 96.062) * (scl) / c.ks);
   arg = 1590.2 * invtk - 12.641 + 1.525 * sqrtis + log_1_m_1p005em3_s + log_1_p_tot_sulfate_div_ks;
-  c.kf = exp(arg);
-  if (deep)
-    c.kf = c.kf * millero_kfac(-9.78 - (0.009 + 0.000942 * temp) * temp, (-3.91 + 0.054 * temp) * p001, press_bar, invRtk);
+  c.kf = OBGC_K_AT_PRESSURE(arg, deep, -9.78 - (0.009 + 0.000942 * temp) * temp, (-3.91 + 0.054 * temp) * p001, press_bar, invRtk);
   // total borate, sulfate, fluoride (773-775)
   c.bt = 0.000232 / 10.811 * scl;
   c.st = 0.14 / 96.062 * scl;
@@ -339,18 +341,13 @@ __device__ __forceinline__ void comp_co3_sat_vals(bool deep, double depth, doubl
   const double s15 = sqrts * salt_lim;
   double arg = -171.9065 - 0.077993 * tk + 2839.319 * invtk + 71.595 * log10tk +
                (-0.77712 + 0.0028426 * tk + 178.34 * invtk) * sqrts - 0.07711 * salt_lim + 0.0041249 * s15;
-  double K_calc = exp(OBGC_LN10 * arg);
+  const double press_bar = deep ? press_bar_of(depth) : 0.0;
+  const double deltaV = -48.76 + 0.5304 * temp;
+  const double Kappa = (-11.76 + 0.3692 * temp) * p001;
+  const double K_calc = OBGC_K_AT_PRESSURE(OBGC_LN10 * arg, deep, deltaV, Kappa, press_bar, invRtk);
   arg = -171.945 - 0.077993 * tk + 2903.293 * invtk + 71.595 * log10tk +
         (-0.068393 + 0.0017276 * tk + 88.135 * invtk) * sqrts - 0.10018 * salt_lim + 0.0059415 * s15;
-  double K_arag = exp(OBGC_LN10 * arg);
-  if (deep) {
-    const double press_bar = press_bar_of(depth);
-    double deltaV = -48.76 + 0.5304 * temp;
-    const double Kappa = (-11.76 + 0.3692 * temp) * p001;
-    K_calc = K_calc * millero_kfac(deltaV, Kappa, press_bar, invRtk);
-    deltaV = deltaV + 2.8;
-    K_arag = K_arag * millero_kfac(deltaV, Kappa, press_bar, invRtk);
-  }
+  const double K_arag = OBGC_K_AT_PRESSURE(OBGC_LN10 * arg, deep, deltaV + 2.8, Kappa, press_bar, invRtk);
   const double inv_Ca = (35.0 / 0.01028) / salt_lim;
   sat_calc = (K_calc * inv_Ca) * OBGC_MASS_TO_VOL;
   sat_arag = (K_arag * inv_Ca) * OBGC_MASS_TO_VOL;
