@@ -1,0 +1,38 @@
+# A wider net than the test-suite casts: GPU vs oracle over many blocks of synthetic columns (cold call, then a warm call on
+# perturbed tracers with the previous pH), 60 and 100 levels, worst case per class.  ~2 minutes, mostly oracle time.
+# python tools/parity_soak.py [blocks]      (on an MI355X; the oracle only checks here)
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from __graft_entry__ import load_pkg
+load_pkg()
+import parity as P
+from ocean_bgc_amd import synth
+from ocean_bgc_amd.modules import ColumnEngine
+from oracle import orabind
+nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+E, O = ColumnEngine(0, path="device_colfast"), orabind.Oracle()
+worst, bad = {}, 0
+for b in range(nblocks):
+    nz = 100 if b % 3 == 2 else 60
+    nc, col0 = 8000, 1_000_003 * b + 17
+    syn = synth.generate(nc, nz, col0=col0)
+    tr = synth.bgc_tracer_array(syn)
+    rest = (syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"], syn["sw"])
+    z = np.zeros((nc, nz))
+    g1, o1 = E.BGC_SourceSink(tr, *rest, z, z), O.bgc_source_sink(tr, *rest, z, z)
+    tr2 = tr * (1.0 + 1e-3 * np.cos(np.arange(tr.size).reshape(tr.shape)))
+    # warm call: both sides start from the ORACLE's previous pH, so the brackets are identical
+    g2 = E.BGC_SourceSink(tr2, *rest, o1["ph_prev"], o1["ph_prev_alt"], alt_co2_use_eco=False)
+    o2 = O.bgc_source_sink(tr2, *rest, o1["ph_prev"], o1["ph_prev_alt"], alt_co2_use_eco=False)
+    for tag, g, o in (("cold", g1, o1), ("warm", g2, o2)):
+        rep = P.compare_bgc(g, o, dz=syn["dz"])
+        bad += 0 if rep.ok() else 1
+        for k, v in rep.summary().items():
+            if v["max"] >= worst.get(k, (-1.0, ""))[0]:
+                worst[k] = (v["max"], "%s block %d (%s, col0=%d, nz=%d)" % (v["at"], b, tag, col0, nz))
+    print("block %d nz=%d done, failures so far %d" % (b, nz, bad), flush=True)
+print("kernel rev", open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip(), "blocks", nblocks, "FAILURES", bad)
+for k, v in worst.items():
+    print("  %-12s %.3e  %s" % (k, v[0], v[1]))
