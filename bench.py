@@ -1,28 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: column-level tracer updates/s of the BGC column hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--diag full|none]
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--diag full|none] [--ph cold|warm]
 
-One "step" = one pass of the hot path over one batch of synthetic columns resident in HBM
-in the engine's native column-fastest layout: BGC_SourceSink (cfg2), + BGC_SurfaceFluxes
-(cfg3), + DMS_SourceSink + MACROS_SourceSink (cfg4), everything (cfg5).  Every timed step
-starts from a COLD pH state (PH_PREV = 0) in freshly zeroed state buffers.
+One "step" = one pass of the hot path over one batch of synthetic columns resident in HBM in the engine's native
+column-fastest layout.  The default workload is the largest single-GPU configuration of BASELINE.json, cfg4:
+1 M columns x 80 levels, BGC_SourceSink + DMS_SourceSink + MACROS_SourceSink (one fused call when the library offers it),
+every diagnostic written like the reference does, a COLD pH state (PH_PREV = 0) at every timed step.
+cfg2 = 100 k x 60 BGC only, cfg3 = 1 M x 60 BGC + BGC_SurfaceFluxes, cfg5 = 1 M x 100 per GPU, every routine.
 One update = one prognostic tendency value of one active cell (30 BGC + 2 DMS + 3 MACROS).
 
-N > 1: one process per GPU (torch.distributed / RCCL used ONLY for the barrier and the
-max-over-ranks of the wall time); columns are independent, so rank r owns global columns
-[r*ncol, (r+1)*ncol) and there is no data-path collective.  Scaling is WEAK: the per-GPU
-batch is fixed.
+N > 1: one process per GPU.  Started by a launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the process is one
+rank; started plainly as `python bench.py --gpus N` it starts its own N ranks -- before touching any GPU -- and relays
+rank 0's line.  torch.distributed (RCCL) only provides the barrier and the max-over-ranks of the wall time: columns are
+independent, rank r owns global columns [r*ncol, (r+1)*ncol), there is no data-path collective.  Scaling is WEAK (the
+per-GPU batch is fixed) unless --scaling strong splits the configuration's columns over the ranks.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the step measured
-with HIP events on the engine's own streams; `cpu_baseline` times the reference arithmetic
-(oracle/_ref = the unmodified Fortran, else the C restatement) on host cores over a bounded
-column sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the step, timed with HIP events on the
+engine's own streams; `cpu_baseline` times the reference arithmetic (oracle/_ref = the unmodified Fortran, else the C
+restatement) on host cores over a bounded column sample of the same workload; `other_workloads` (N = 1 only) holds short
+runs of cfg2, cfg3 and the warm-bracket variant of the headline workload.
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,24 +40,37 @@ CONFIGS = {
     "cfg4": (1_000_000, 80, ("bgc", "dms", "macros")),
     "cfg5": (1_000_000, 100, ("bgc", "surf", "dms", "dms_surf", "macros")),
 }
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0          # HBM3E 8 TB/s spec (6.3 TB/s is what a streaming copy reaches on this part)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, FMA counted as 2
 
-# algorithmic bytes per ACTIVE cell (split per kernel in DESIGN.md)
-BYTES_CARBONATE = {"none": 88, "full": 168}
-BYTES_ECOSYS = {"none": 472, "full": 1432}     # PAR scan + cell kernel + particle sweep together
-# the cell kernel alone: reads 27 tracers + T, dz, zmid, writes 19 final tendencies (+ 10 staged ones, 4 hand-off
-# scratch values and the 3 light planes it reads back, all engine-internal, not algorithmic); with diagnostics
-# it also writes the 72 per-autotroph and 21 of the (k,column) diagnostics and reads S and zbot(k-1)
-BYTES_CELL = {"none": (27 + 3 + 19) * 8, "full": (27 + 5 + 19 + 72 + 21) * 8}
+# ALGORITHMIC bytes per ACTIVE cell: every array of the routine touched once, fp64.
+#   BGC_SourceSink: 38 inputs + 32 outputs = 560 B; + 130 diagnostic values = 1600 B
+#   DMS_SourceSink: 14 tracers + dz in, 2 tendencies out = 136 B; + 27 diagnostics = 352 B
+#   MACROS_SourceSink: 8 tracers in, 3 tendencies out = 88 B; + 6 diagnostics = 136 B
+#   the three fused, shared tracers read once: 43 in + 37 out = 640 B; + 163 diagnostics = 1944 B
+BYTES_BGC = {"none": 560, "full": 1600}
+BYTES_CARBONATE = {"none": 88, "full": 168}      # the carbonate block's share of BYTES_BGC
 BYTES_DMS = {"none": 136, "full": 352}
 BYTES_MACROS = {"none": 88, "full": 136}
+BYTES_FUSED = {"none": 640, "full": 1944}
+# the ecosystem cell kernel alone: reads 27 tracers + T, dz, zmid, writes 19 final tendencies; with diagnostics it also
+# writes the 72 per-autotroph and 21 of the (k,column) diagnostics and reads S and zbot(k-1)
+BYTES_CELL = {"none": (27 + 3 + 19) * 8, "full": (27 + 5 + 19 + 72 + 21) * 8}
+# the DMS / MACROS terms folded into it by the fused step: 2 + 3 own tracers in, 2 + 3 tendencies out (+ 27 + 6 diagnostics)
+BYTES_CELL_DM = {"none": 10 * 8, "full": (10 + 33) * 8}
 
 
 def shard(rank, world, ncol_per_gpu):
-    """Static column-range partition: rank r owns global columns
-    [r*ncol, (r+1)*ncol).  Weak scaling: the per-GPU batch does not depend on `world`."""
+    """Static column-range partition: rank r owns global columns [r*ncol, (r+1)*ncol).  Weak scaling: the per-GPU
+    batch does not depend on `world`."""
     return rank * ncol_per_gpu, ncol_per_gpu
+
+
+def shard_strong(rank, world, total):
+    """--scaling strong: the configuration's columns split over the ranks; the last rank takes what is left."""
+    per = (total + world - 1) // world
+    col0 = rank * per
+    return col0, max(0, min(per, total - col0))
 
 
 def reduce_results(dist, elapsed, updates, device):
@@ -68,8 +85,9 @@ def reduce_results(dist, elapsed, updates, device):
     return float(t.item()), float(u.item())
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_worker(job):
-    """Runs in a child process: reference arithmetic on one column slice; returns (updates, seconds)."""
+    """Runs in a child process: reference arithmetic on one column slice; returns (updates, cold seconds, warm seconds)."""
     kind, col0, nc, nz, modules = job
     sys.path.insert(0, ROOT)
     import numpy as np
@@ -86,45 +104,68 @@ def _cpu_worker(job):
     tr = synth.bgc_tracer_array(syn)
     z = np.zeros((nc, nz))
     cells = int(np.minimum(syn["kmax"], nz).clip(0).sum())
-    upd, sec = 0, 0.0
-    t0 = time.perf_counter()
-    res = R.bgc_source_sink(tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
-                            syn["fesed"], syn["dust"], syn["sw"], z, z)
-    sec += res.get("seconds", time.perf_counter() - t0)
-    upd += 30 * cells
     f = syn["forcing"]
-    if "surf" in modules:
+    dtr = synth.dms_tracer_array(syn) if ("dms" in modules or "dms_surf" in modules) else None
+    mtr = synth.macros_tracer_array(syn) if "macros" in modules else None
+
+    def one_pass(tr, php, pha, forcing):
+        upd, sec = 0, 0.0
         t0 = time.perf_counter()
-        r2 = R.bgc_surface_fluxes(tr, f, syn["depositionFlux"], syn["riverFlux"], syn["gasFlux"], syn["seaIceFlux"])
-        sec += r2.get("seconds", time.perf_counter() - t0)
-    if "dms" in modules:
-        dtr = synth.dms_tracer_array(syn)
-        t0 = time.perf_counter()
-        r3 = R.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"])
-        sec += r3.get("seconds", time.perf_counter() - t0)
-        upd += 2 * cells
-    if "macros" in modules:
-        mtr = synth.macros_tracer_array(syn)
-        t0 = time.perf_counter()
-        r4 = R.macros_source_sink(mtr, syn["kmax"])
-        sec += r4.get("seconds", time.perf_counter() - t0)
-        upd += 3 * cells
-    return upd, sec
+        res = R.bgc_source_sink(tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
+                                syn["fesed"], syn["dust"], syn["sw"], php, pha)
+        sec += res.get("seconds", time.perf_counter() - t0)
+        upd += 30 * cells
+        r2 = None
+        if "surf" in modules:
+            t0 = time.perf_counter()
+            r2 = R.bgc_surface_fluxes(tr, forcing, syn["depositionFlux"], syn["riverFlux"], syn["gasFlux"], syn["seaIceFlux"])
+            sec += r2.get("seconds", time.perf_counter() - t0)
+        if "dms" in modules:
+            t0 = time.perf_counter()
+            r3 = R.dms_source_sink(dtr, syn["dz"], syn["kmax"], f["SST"], syn["sw"])
+            sec += r3.get("seconds", time.perf_counter() - t0)
+            upd += 2 * cells
+        if "dms_surf" in modules:
+            t0 = time.perf_counter()
+            r5 = R.dms_surface_fluxes(dtr, f)
+            sec += r5.get("seconds", time.perf_counter() - t0)
+        if "macros" in modules:
+            t0 = time.perf_counter()
+            r4 = R.macros_source_sink(mtr, syn["kmax"])
+            sec += r4.get("seconds", time.perf_counter() - t0)
+            upd += 3 * cells
+        return upd, sec, res, r2
+
+    upd, cold, res, r2 = one_pass(tr, z, z, f)
+    # warm: the previous pH is the bracket centre and every tracer has moved a little, as in a running model
+    tr2 = tr * (1.0 + 1.0e-3 * np.sin(np.arange(tr.size).reshape(tr.shape)))
+    _, warm, _, _ = one_pass(tr2, res["ph_prev"], res["ph_prev_alt"], r2["forcing"] if r2 is not None else f)
+    return upd, cold, warm
 
 
-def cpu_baseline(nz, modules, target_core_seconds=20.0):
-    """Reference arithmetic on host cores: P processes (the reference keeps module state,
-    co2calc.F90:65-67, so processes not threads), static column split of a bounded sample."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(nz, modules, seconds_per_worker=3.0):
+    """Reference arithmetic on host cores: P processes (the reference keeps module state, co2calc.F90:65-67, so processes
+    not threads), static column split of a bounded sample of the same workload; cold pass then warm pass."""
     from oracle import refbind
     kind = "reference" if refbind.available() else "port"
     if kind == "port":
         from oracle import orabind
         if not orabind.available():
             orabind.build()
-    cores = max(1, min(16, (os.cpu_count() or 1)))
-    per_cell_us = 5.0 * (nz / 60.0) ** 0 * (1.0 + 0.15 * ("dms" in modules))     # ~5 us / cell / core (SURVEY section 6)
-    ncol_total = int(target_core_seconds / (per_cell_us * 1e-6 * nz))
-    per = max(64, ncol_total // cores)
+    ncpu = os.cpu_count() or 1
+    cores = max(1, min(16, ncpu))          # a one-GPU box's CPU share is 16 cores whatever the machine has
+    per_cell_us = 5.0 * (1.0 + 0.15 * ("dms" in modules) + 0.05 * ("macros" in modules))     # ~5 us / cell / core
+    per = max(64, int(seconds_per_worker / (per_cell_us * 1e-6 * nz)))
     jobs = [(kind, i * per, per, nz, tuple(modules)) for i in range(cores)]
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
@@ -132,10 +173,288 @@ def cpu_baseline(nz, modules, target_core_seconds=20.0):
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     upd = sum(r[0] for r in res)
-    slowest = max(r[1] for r in res)
-    return {"value": upd / slowest, "unit": "updates/s", "cores": cores, "kind": kind,
-            "sample": "%d columns x %d levels (%d per process, %d processes), cold pH, modules=%s; per-core %.3g updates/s; pool wall %.1f s"
-                      % (per * cores, nz, per, cores, "+".join(modules), upd / slowest / cores, wall)}
+    cold = max(r[1] for r in res)
+    warm = max(r[2] for r in res)
+    return {"value": upd / cold, "unit": "updates/s", "cores": cores, "kind": kind, "warm_value": upd / warm,
+            "sample": "%d columns x %d levels (%d per process, %d processes of %d logical CPUs, %s), modules=%s, cold pH then "
+                      "warm pH; slowest process %.2f s cold / %.2f s warm; per-core %.3g updates/s cold; pool wall %.1f s"
+                      % (per * cores, nz, per, cores, ncpu, _cpu_model(), "+".join(modules), cold, warm, upd / cold / cores, wall)}
+
+
+# ------------------------------------------------------------------------------------------------ GPU workload
+class Workload:
+    """Device-resident inputs and outputs of one configuration, generated on the device (bit-identical to synth.py)."""
+
+    def __init__(self, eng, torch, L, name, ncol, nz, modules, col0, diag_on, ph, steps, fused):
+        self.eng, self.torch, self.L = eng, torch, L
+        self.name, self.ncol, self.nz, self.modules, self.diag_on, self.ph = name, ncol, nz, modules, diag_on, ph
+        dev = torch.device("cuda", torch.cuda.current_device())
+        f64 = dict(dtype=torch.float64, device=dev)
+        E = torch.empty
+        self.tr = E((30, nz, ncol), **f64)
+        self.kc = {nm: E((nz, ncol), **f64) for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesedflux")}
+        self.cc = {nm: E((ncol,), **f64) for nm in ("lat", "dust_flux_in", "sw_flux")}
+        self.kmax = E((ncol,), dtype=torch.int32, device=dev)
+        eng.synth_fill(nz, ncol, col0, tracers=self.tr, kmax=self.kmax, **self.kc, **self.cc)
+        self.tend = E((30, nz, ncol), **f64)
+        # cold start per step: a zeroed pH state pair per step, rotated over at most 8 buffers
+        self.nbuf = 1 if ph == "warm" else max(1, min(steps, 8))
+        self.phs = [torch.zeros((2, nz, ncol), **f64) for _ in range(self.nbuf)]
+        self.diag = None
+        if diag_on:
+            d = {}
+            for nm in L.BGC_DIAG_KC:
+                if nm not in L.BGC_DIAG_KC_UNTOUCHED:
+                    d[nm] = E((nz, ncol), **f64)
+            for nm in L.BGC_DIAG_KCA:
+                d[nm] = E((4, nz, ncol), **f64)
+            for nm in L.BGC_DIAG_CA:
+                d[nm] = E((4, ncol), **f64)
+            for nm in L.BGC_DIAG_C:
+                d[nm] = E((ncol,), **f64)
+            self.diag = d
+        self.surf = self.dms = self.macros = None
+        extra = {}
+        if "surf" in modules or "dms_surf" in modules:
+            s = {nm: E((ncol,), **f64) for nm in ("surfacePressure", "iceFraction", "windSpeedSquared10m", "atmCO2", "atmCO2_ALT_CO2",
+                                                  "surfaceDepth", "SST", "SSS", "surface_pH", "surface_pH_alt_co2")}
+            flux = {nm: E((30, ncol), **f64) for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")}
+            extra.update(s)
+            extra.update(flux)
+            self.surf = dict(forcing=s, flux=[flux[nm] for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")],
+                             flux0=None, ice0=None, net=E((30, ncol), **f64),
+                             diag={nm: E((ncol,), **f64) for nm in L.BGC_FLUX_DIAG} if diag_on else None)
+        own = None
+        if "dms" in modules or "macros" in modules or "dms_surf" in modules:
+            own = E((5, nz, ncol), **f64)
+            extra.update(dms=own[0], dmsp=own[1], prot=own[2], poly=own[3], lip=own[4])
+        if extra:
+            eng.synth_fill_extra(nz, ncol, col0, **extra)
+        self.fused = bool(fused) and ("dms" in modules and "macros" in modules) and hasattr(eng, "fused_step")
+        if "dms" in modules or "dms_surf" in modules:
+            dtr = None
+            if not self.fused or "dms_surf" in modules:     # the separate entry points read a 14-plane DMS tracer array
+                dtr = E((14, nz, ncol), **f64)
+                dtr[0].copy_(own[0]); dtr[1].copy_(own[1])
+                for j, nm in enumerate(L.DMS_TRACERS[2:], start=2):
+                    dtr[j].copy_(self.tr[L.BGC_TRACERS.index(nm)])
+            self.dms = dict(tr=dtr, own=own[0:2], tend=E((2 if self.fused else 14, nz, ncol), **f64),
+                            diag={nm: E((nz, ncol), **f64) for nm in L.DMS_DIAG_KC} if diag_on else None,
+                            sst=self.kc["temp"][0].contiguous(),
+                            net=E((14, ncol), **f64) if "dms_surf" in modules else None,
+                            fdiag={nm: E((ncol,), **f64) for nm in L.DMS_FLUX_DIAG} if ("dms_surf" in modules and diag_on) else None)
+        if "macros" in modules:
+            mtr = None
+            if not self.fused:
+                mtr = E((8, nz, ncol), **f64)
+                for j in range(3):
+                    mtr[j].copy_(own[2 + j])
+                for j, nm in enumerate(L.MACROS_TRACERS[3:], start=3):
+                    mtr[j].copy_(self.tr[L.BGC_TRACERS.index(nm)])
+            self.macros = dict(tr=mtr, own=own[2:5], tend=E((3 if self.fused else 8, nz, ncol), **f64),
+                               diag={nm: E((nz, ncol), **f64) for nm in L.MACROS_DIAG_KC} if diag_on else None)
+        self.active_cells = int(torch.clamp(self.kmax, 0, nz).sum().item())
+        self.per_cell = 30 + (2 if "dms" in modules else 0) + (3 if "macros" in modules else 0)
+        self.updates_per_step = self.active_cells * self.per_cell
+        CF = L.OBGC_LAYOUT_COLFAST
+        kc, cc = self.kc, self.cc
+        # the argument blocks of the calls are built once, as a compiled host would: the arrays do not move between steps
+        if self.fused:
+            self.prepared = [eng.fused_step_prepare(nz, ncol, CF, self.tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"],
+                                                    cc["lat"], self.kmax, kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"],
+                                                    self.tend, p[0], p[1], self.diag, True,
+                                                    dms=self.dms["own"][0], dmsp=self.dms["own"][1], SST=self.dms["sst"],
+                                                    dms_tend=self.dms["tend"][0], dmsp_tend=self.dms["tend"][1], dms_diag=self.dms["diag"],
+                                                    prot=self.macros["own"][0], poly=self.macros["own"][1], lip=self.macros["own"][2],
+                                                    prot_tend=self.macros["tend"][0], poly_tend=self.macros["tend"][1],
+                                                    lip_tend=self.macros["tend"][2], macros_diag=self.macros["diag"])
+                             for p in self.phs]
+        else:
+            self.prepared = [eng.bgc_source_sink_prepare(nz, ncol, CF, self.tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"],
+                                                         cc["lat"], self.kmax, kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"],
+                                                         self.tend, p[0], p[1], self.diag, True)
+                             for p in self.phs]
+        self.kms = {"call": [], "carbonate": [], "ecosys": [], "cell": [], "dms": [], "macros": []}
+        torch.cuda.synchronize()
+        if self.surf is not None:
+            # BGC_SurfaceFluxes scales the Fe rows of its flux arrays and clamps iceFraction IN PLACE: every step starts
+            # from the generated values again (4 short device copies per step, inside the timing)
+            self.surf["flux0"] = [x.clone() for x in self.surf["flux"]]
+            self.surf["ice0"] = self.surf["forcing"]["iceFraction"].clone()
+
+    def step(self, i, record):
+        eng, L, torch = self.eng, self.L, self.torch
+        CF = L.OBGC_LAYOUT_COLFAST
+        nz, ncol = self.nz, self.ncol
+        if self.surf is not None:
+            e = self.surf
+            if self.ph == "cold":
+                e["forcing"]["surface_pH"].zero_(); e["forcing"]["surface_pH_alt_co2"].zero_()
+            for x, x0 in zip(e["flux"], e["flux0"]):
+                x.copy_(x0)
+            e["forcing"]["iceFraction"].copy_(e["ice0"])
+            torch.cuda.synchronize()      # torch's stream -> engine's streams
+            if "surf" in self.modules:     # the host model calls *_SurfaceFluxes before *_SourceSink
+                eng.bgc_surface_fluxes(nz, ncol, CF, self.tr, e["forcing"], *e["flux"], e["net"], e["diag"])
+            if "dms_surf" in self.modules:
+                d = self.dms
+                eng.dms_surface_fluxes(nz, ncol, CF, d["tr"], e["forcing"], d["net"], d["fdiag"])
+        if self.fused:
+            eng.fused_step_run(self.prepared[i % self.nbuf])
+        else:
+            eng.bgc_source_sink_run(self.prepared[i % self.nbuf])
+        if record:
+            k = self.kms
+            k["call"].append(eng.last_kernel_ms(0)); k["carbonate"].append(eng.last_kernel_ms(1))
+            k["ecosys"].append(eng.last_kernel_ms(2)); k["cell"].append(eng.last_kernel_ms(4))
+        if not self.fused:
+            if "dms" in self.modules:
+                d = self.dms
+                eng.dms_source_sink(nz, ncol, CF, d["tr"], self.kc["dz"], self.kmax, d["sst"], self.cc["sw_flux"], d["tend"], d["diag"])
+                if record:
+                    self.kms["dms"].append(eng.last_kernel_ms(0))
+            if "macros" in self.modules:
+                m = self.macros
+                eng.macros_source_sink(nz, ncol, CF, m["tr"], self.kmax, m["tend"], m["diag"])
+                if record:
+                    self.kms["macros"].append(eng.last_kernel_ms(0))
+
+    def rezero(self):
+        for p in self.phs:
+            p.zero_()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, barrier):
+        torch = self.torch
+        torch.cuda.synchronize()              # inputs were produced on torch's stream / the engine's stream
+        for i in range(warmup):
+            self.step(i, False)
+        if self.ph == "cold":
+            self.rezero()
+        elif warmup == 0:
+            self.step(0, False)               # a warm measurement needs one untimed call to have a previous pH
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(i, True)                # engine calls are synchronous: each returns with its kernels done
+            if self.ph == "cold" and (i + 1) % self.nbuf == 0 and i + 1 < steps:
+                self.rezero()                 # keeps every timed step cold; 2 small memsets per 8 steps, inside the timing
+        barrier()
+        return time.perf_counter() - t0
+
+    def workload_name(self):
+        return ("%s: %d columns x %d levels per GPU, %s%s, native column-fastest layout, diagnostics=%s, %s"
+                % (self.name, self.ncol, self.nz, "+".join(self.modules), " (one fused call)" if self.fused else "",
+                   "full" if self.diag_on else "none",
+                   "cold pH bracket every step" if self.ph == "cold" else "warm pH brackets (previous step)"))
+
+
+def short_run(eng, torch, L, name, diag_on, ph, steps, warmup, fused):
+    ncol, nz, modules = CONFIGS[name]
+    w = Workload(eng, torch, L, name, ncol, nz, modules, 0, diag_on, ph, steps, fused)
+    el = w.timed(steps, warmup, torch.cuda.synchronize)
+    out = {"workload": w.workload_name(), "value": w.updates_per_step * steps / el, "unit": "updates/s", "steps": steps,
+           "ms_per_step": el / steps * 1e3}
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+def roofline_of(w, eng, args, ROOT):
+    """The dominant kernel of the step = the longest single launch."""
+    import numpy as np
+    dk = "full" if w.diag_on else "none"
+    mean = lambda v: float(np.mean(v)) if v else 0.0
+    k = w.kms
+    t_car, t_eco, t_call, t_cell = mean(k["carbonate"]), mean(k["ecosys"]), mean(k["call"]), mean(k["cell"])
+    sched = eng.last_schedule() if hasattr(eng, "last_schedule") else -1
+    cand = {}
+    b_cell = BYTES_CELL[dk] + (BYTES_CELL_DM[dk] if w.fused else 0)
+    if sched == 2:      # the carbonate system is solved inside the cell kernel's wavefronts: one launch does both
+        cand["bgc_cell_kernel(+carbonate%s)" % ("+dms+macros" if w.fused else "")] = (t_cell, b_cell + BYTES_CARBONATE[dk])
+    elif sched == 3:    # the column-block kernel does the whole ecosystem (+ carbonate) in one launch
+        cand["bgc_column_kernel"] = (t_cell, (BYTES_FUSED[dk] if w.fused else BYTES_BGC[dk]))
+    else:
+        cand["bgc_cell_kernel%s" % ("(+dms+macros)" if w.fused else "")] = (t_cell, b_cell)
+        cand["bgc_carbonate_kernel"] = (t_car, BYTES_CARBONATE[dk])
+    dom = max(cand, key=lambda n: cand[n][0])
+    t_dom, b_dom = cand[dom]
+    achieved = w.active_cells * b_dom / (t_dom * 1e-3) / 1e9 if t_dom > 0 else 0.0
+    step_bytes = (BYTES_FUSED[dk] if ("dms" in w.modules and "macros" in w.modules) else
+                  BYTES_BGC[dk] + (BYTES_DMS[dk] if "dms" in w.modules else 0) + (BYTES_MACROS[dk] if "macros" in w.modules else 0))
+    t_step = t_call + mean(k["dms"]) + mean(k["macros"])
+    # HBM bytes per launch and fp64 VALU utilisation from the rocprofv3 PMC passes of THIS kernel revision and workload
+    # (profiles/pmc_traffic.json, profiles/valu.json, written by tools/pmc_summary.py); null when they belong to another
+    traffic = valu = None
+    try:
+        rev = open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip()
+        key = "%s_%s" % (w.name, dk)
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tab.get("kernel_rev") == rev and not args.columns:
+            base = dom.split("(")[0]
+            traffic = tab["runs"][key][base]["total"]
+        vt = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+        if vt.get("kernel_rev") == rev and not args.columns:
+            valu = {kk: round(v["valu_busy"], 3) for kk, v in vt["runs"][key].items()}
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "fp64_valu_busy": valu,
+            "algorithmic_bytes_per_launch": w.active_cells * b_dom, "algorithmic_bytes_per_cell": b_dom,
+            "active_cells_per_launch": w.active_cells, "avg_launch_ms": t_dom, "schedule": sched,
+            "kernel_ms": {"bgc_carbonate_kernel": t_car, "bgc_cell_kernel": t_cell, "ecosystem_light+cell+sweep": t_eco,
+                          "bgc_call_device_ms": t_call, "dms_call_device_ms": mean(k["dms"]), "macros_call_device_ms": mean(k["macros"])},
+            "whole_step": {"algorithmic_bytes_per_cell": step_bytes, "device_ms": t_step,
+                           "GBps": w.active_cells * step_bytes / (t_step * 1e-3) / 1e9 if t_step > 0 else 0.0,
+                           "frac": (w.active_cells * step_bytes / (t_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_step > 0 else 0.0},
+            "note": "frac prices the dominant kernel's ALGORITHMIC bytes against the 8 TB/s spec; whole_step does the same for "
+                    "every kernel of the step together (device time of the calls); the carbonate solve is bound by fp64 VALU "
+                    "issue, not by HBM"}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's line.
+    The parent never touches a GPU: torch.cuda.device_count() only counts."""
+    n = args.gpus
+    share = os.environ.get("OBGC_BENCH_SHARE_GPU", "0") == "1"
+    import torch
+    have = torch.cuda.device_count()
+    if have < 1 or (have < n and not share):
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible\n" % (n, have))
+        return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OBGC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d rc %d" % b for b in bad))
+        return 1
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None or json.loads(line).get("n_gpus") != n:
+        sys.stderr.write("bench.py: rank 0 printed no result line for %d GPUs\n" % n)
+        return 1
+    print(line)
+    return 0
 
 
 def main():
@@ -143,34 +462,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--diag", default="full", choices=("full", "none"),
-                    help="full: all 96 diagnostics written like the reference does; none: tendencies + pH state only")
+                    help="full: every diagnostic written like the reference does; none: tendencies + pH state only")
     ap.add_argument("--ph", default="cold", choices=("cold", "warm"),
-                    help="cold (headline): PH_PREV_* = 0 at every step, full [6, 9] bracket; warm (secondary timing of "
-                         "SURVEY.md 8d): the previous step's pH is the bracket centre, as in a running model")
+                    help="cold (headline): PH_PREV_* = 0 at every step, full [6, 9] bracket; warm: the previous step's pH is "
+                         "the bracket centre, as in a running model")
     ap.add_argument("--columns", type=int, default=0, help="override columns per GPU")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
-                    help="weak (default, what the driver's scaling run uses): the config's columns on EVERY GPU; strong: "
-                         "the config's columns split over the GPUs (SURVEY.md 8d asks for both at cfg5)")
+                    help="weak (default, what a scaling run uses): the config's columns on EVERY GPU; strong: the config's "
+                         "columns split over the GPUs")
+    ap.add_argument("--separate", action="store_true", help="cfg4 / cfg5: three separate calls instead of the fused step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short cfg2 / cfg3 / warm-bracket runs of the N = 1 line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    import numpy as np
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(env_world)
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
     import torch
     from __graft_entry__ import load_pkg
     load_pkg()
     from ocean_bgc_amd import _lib as L
     from ocean_bgc_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    # rehearsal on a 1-GPU box: OBGC_BENCH_SHARE_GPU=1 maps every rank onto GPU 0 and uses gloo for the
+    # rehearsal on a 1-GPU box: OBGC_BENCH_SHARE_GPU=1 maps every rank onto GPU 0 and uses gloo (CPU tensors) for the
     # barrier / max-reduce (RCCL refuses two ranks on one device); the timed path is otherwise identical
     share = os.environ.get("OBGC_BENCH_SHARE_GPU", "0") == "1"
     if share:
@@ -194,98 +523,12 @@ def main():
     if args.columns:
         ncol = args.columns
     if args.scaling == "strong":
-        total = ncol
-        ncol = (total + world - 1) // world          # the last rank takes what is left
-        col0 = rank * ncol
-        ncol = max(0, min(ncol, total - col0))
+        col0, ncol = shard_strong(rank, world, ncol)
     else:
         col0, ncol = shard(rank, world, ncol)
     diag_on = args.diag == "full"
     eng = Engine(local_rank)
-    f64 = dict(dtype=torch.float64, device=dev)
-
-    # ---- inputs: generated on the device, native [plane][level][column] layout ----
-    tr = torch.empty((30, nz, ncol), **f64)
-    kc = {nm: torch.empty((nz, ncol), **f64) for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesedflux")}
-    cc = {nm: torch.empty((ncol,), **f64) for nm in ("lat", "dust_flux_in", "sw_flux")}
-    kmax = torch.empty((ncol,), dtype=torch.int32, device=dev)
-    eng.synth_fill(nz, ncol, col0, tracers=tr, kmax=kmax, **kc, **cc)
-    tend = torch.empty((30, nz, ncol), **f64)
-    # cold start per step: a zeroed pH state pair per step, rotated over at most 8 buffers
-    nbuf = 1 if args.ph == "warm" else max(1, min(args.steps, 8))
-    ph = [torch.zeros((2, nz, ncol), **f64) for _ in range(nbuf)]
-    diag = None
-    if diag_on:
-        diag = {}
-        for nm in L.BGC_DIAG_KC:
-            if nm not in L.BGC_DIAG_KC_UNTOUCHED:
-                diag[nm] = torch.empty((nz, ncol), **f64)
-        for nm in L.BGC_DIAG_KCA:
-            diag[nm] = torch.empty((4, nz, ncol), **f64)
-        for nm in L.BGC_DIAG_CA:
-            diag[nm] = torch.empty((4, ncol), **f64)
-        for nm in L.BGC_DIAG_C:
-            diag[nm] = torch.empty((ncol,), **f64)
-    extra = {}
-    if "surf" in modules:
-        s = {nm: torch.empty((ncol,), **f64) for nm in ("surfacePressure", "iceFraction", "windSpeedSquared10m", "atmCO2",
-                                                       "atmCO2_ALT_CO2", "surfaceDepth", "SST", "SSS")}
-        u = torch.rand((ncol,), **f64)
-        s["surfacePressure"].fill_(1.0); s["iceFraction"].copy_(0.3 * u); s["windSpeedSquared10m"].copy_(((3 + 12 * u) * 100) ** 2)
-        s["atmCO2"].fill_(400.0); s["atmCO2_ALT_CO2"].fill_(280.0); s["surfaceDepth"].fill_(5.0)
-        s["SST"].copy_(kc["temp"][0]); s["SSS"].copy_(kc["salt"][0])
-        s["surface_pH"] = torch.zeros((ncol,), **f64); s["surface_pH_alt_co2"] = torch.zeros((ncol,), **f64)
-        extra["surf"] = dict(forcing=s, flux=[torch.full((30, ncol), 1e-9, **f64) for _ in range(4)],
-                             net=torch.empty((30, ncol), **f64),
-                             diag={nm: torch.empty((ncol,), **f64) for nm in L.BGC_FLUX_DIAG} if diag_on else None)
-    if "dms" in modules:
-        dtr = torch.empty((14, nz, ncol), **f64)
-        dtr[0].fill_(2e-3); dtr[1].fill_(5e-3)
-        for j, nm in enumerate(L.DMS_TRACERS[2:], start=2):
-            dtr[j].copy_(tr[L.BGC_TRACERS.index(nm)])
-        extra["dms"] = dict(tr=dtr, tend=torch.empty((14, nz, ncol), **f64),
-                            diag={nm: torch.empty((nz, ncol), **f64) for nm in L.DMS_DIAG_KC} if diag_on else None,
-                            sst=kc["temp"][0].contiguous())
-    if "macros" in modules:
-        mtr = torch.empty((8, nz, ncol), **f64)
-        mtr[0].fill_(1.0); mtr[1].fill_(2.0); mtr[2].fill_(0.1)
-        for j, nm in enumerate(L.MACROS_TRACERS[3:], start=3):
-            mtr[j].copy_(tr[L.BGC_TRACERS.index(nm)])
-        extra["macros"] = dict(tr=mtr, tend=torch.empty((8, nz, ncol), **f64),
-                               diag={nm: torch.empty((nz, ncol), **f64) for nm in L.MACROS_DIAG_KC} if diag_on else None)
-
-    active_cells = int(torch.clamp(kmax, 0, nz).sum().item())
-    per_cell = 30 + (2 if "dms" in modules else 0) + (3 if "macros" in modules else 0)
-    updates_per_step = active_cells * per_cell
-    CF = L.OBGC_LAYOUT_COLFAST
-    kms = {"carbonate": [], "ecosys": [], "call": [], "cell": []}
-
-    # the argument blocks of the calls are built once, as a compiled host would: the arrays do not move between steps
-    prepared = [eng.bgc_source_sink_prepare(nz, ncol, CF, tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"], cc["lat"], kmax,
-                                            kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"], tend, p[0], p[1], diag, True)
-                for p in ph]
-
-    def step(i, record):
-        eng.bgc_source_sink_run(prepared[i % nbuf])
-        if record:
-            kms["call"].append(eng.last_kernel_ms(0)); kms["carbonate"].append(eng.last_kernel_ms(1))
-            kms["ecosys"].append(eng.last_kernel_ms(2)); kms["cell"].append(eng.last_kernel_ms(4))
-        if "surf" in extra:
-            e = extra["surf"]
-            e["forcing"]["surface_pH"].zero_(); e["forcing"]["surface_pH_alt_co2"].zero_()
-            torch.cuda.synchronize()      # torch's stream -> engine's streams
-            eng.bgc_surface_fluxes(nz, ncol, CF, tr, e["forcing"], *e["flux"], e["net"], e["diag"])
-        if "dms" in extra:
-            e = extra["dms"]
-            eng.dms_source_sink(nz, ncol, CF, e["tr"], kc["dz"], kmax, e["sst"], cc["sw_flux"], e["tend"], e["diag"])
-        if "macros" in extra:
-            e = extra["macros"]
-            eng.macros_source_sink(nz, ncol, CF, e["tr"], kmax, e["tend"], e["diag"])
-
-    def rezero():
-        for p in ph:
-            p.zero_()
-        torch.cuda.synchronize()
+    w = Workload(eng, torch, L, args.config, ncol, nz, modules, col0, diag_on, args.ph, args.steps, not args.separate)
 
     def barrier():
         torch.cuda.synchronize()
@@ -293,78 +536,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.cuda.synchronize()              # inputs were produced on torch's stream / the engine's stream
-    for i in range(args.warmup):
-        step(i, False)
-    if args.ph == "cold":
-        rezero()
-    elif args.warmup == 0:
-        step(0, False)                    # a warm measurement needs one untimed call to have a previous pH
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)                     # engine calls are synchronous: each returns with its kernels done
-        if args.ph == "cold" and (i + 1) % nbuf == 0 and i + 1 < args.steps:
-            rezero()                      # keeps every timed step cold; 2 small memsets per 8 steps, inside the timing
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed, updates_all = reduce_results(dist, elapsed, updates_per_step, red_dev)
+    elapsed = w.timed(args.steps, args.warmup, barrier)
+    elapsed, updates_all = reduce_results(dist, elapsed, w.updates_per_step, red_dev)
     value = updates_all * args.steps / elapsed
 
     if rank == 0:
-        dk = args.diag
-        mean = lambda v: float(np.mean(v)) if v else float("nan")
-        t_car, t_eco, t_call, t_cell = mean(kms["carbonate"]), mean(kms["ecosys"]), mean(kms["call"]), mean(kms["cell"])
-        # dominant kernel = the longest single launch: the ecosystem cell kernel or the carbonate kernel
-        if t_cell >= t_car:
-            dom, t_dom, b_dom = "bgc_cell_kernel", t_cell, BYTES_CELL[dk]
-        else:
-            dom, t_dom, b_dom = "bgc_carbonate_kernel", t_car, BYTES_CARBONATE[dk]
-        achieved = active_cells * b_dom / (t_dom * 1e-3) / 1e9
-        # HBM bytes per launch from rocprofv3 PMC passes of this kernel revision (tools/pmc_summary.py);
-        # null when the committed table belongs to another revision / workload
-        traffic = None
-        try:
-            tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            rev = open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip()
-            key = dom
-            if tab.get("kernel_rev") == rev and not args.columns:
-                traffic = tab["runs"]["%s_%s" % (args.config, dk)][key]["total"]
-        except Exception:
-            traffic = None
-        # fp64 VALU issue utilisation of the kernels (SQ_ACTIVE_INST_VALU PMC pass of this kernel revision,
-        # profiles/valu.json): SURVEY.md 8d asks for it next to the HBM fraction
-        valu = None
-        try:
-            vt = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
-            rev = open(os.path.join(ROOT, "ocean-bgc_amd", "KERNEL_REV")).read().strip()
-            if vt.get("kernel_rev") == rev and not args.columns:
-                valu = {k: round(v["valu_busy"], 3) for k, v in vt["runs"]["%s_%s" % (args.config, dk)].items()}
-        except Exception:
-            valu = None
-        roofline = {"bound": "hbm", "kernel": dom, "fp64_valu_busy": valu, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": active_cells * b_dom,
-                    "algorithmic_bytes_per_cell": b_dom, "active_cells_per_launch": active_cells,
-                    "avg_launch_ms": t_dom,
-                    "other_kernel_ms": {"bgc_carbonate_kernel": t_car, "bgc_cell_kernel": t_cell,
-                                        "ecosystem_par+cell+sweep": t_eco, "call_device_ms": t_call},
-                    "whole_call_GBps": active_cells * (BYTES_CARBONATE[dk] + BYTES_ECOSYS[dk]) / (t_call * 1e-3) / 1e9,
-                    "note": "the cell kernel moves `traffic` bytes (hand-off + zero fill on top of the algorithmic "
-                            "ones) at the HBM rate a write-heavy stream reaches; the carbonate kernel beside it is "
-                            "bound by fp64 VALU issue (96 %); see DESIGN.md section 4"}
         out = {"metric": "column-level tracer updates/sec", "value": value, "unit": "updates/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "%s: %d columns x %d levels per GPU, %s, native column-fastest layout, "
-                                      "diagnostics=%s, %s"
-                                      % (args.config, ncol, nz, "+".join(modules), dk,
-                                         "cold pH bracket every step" if args.ph == "cold" else "warm pH brackets (previous step)"),
-                          "columns_per_gpu": ncol, "levels": nz, "active_cells_per_gpu": active_cells,
-                          "updates_per_step_all_gpus": updates_all, "parallelism": "column-range x%d, no collective" % world,
-                          "columns_per_s": ncol * world * args.steps / elapsed,
-                          "cells_per_s": updates_all / per_cell * args.steps / elapsed},
-               "roofline": roofline}
+               "config": {"workload": w.workload_name(), "columns_per_gpu": ncol, "levels": nz,
+                          "active_cells_per_gpu": w.active_cells, "updates_per_step_all_gpus": updates_all,
+                          "parallelism": "column-range x%d, no collective" % world,
+                          "columns_per_s": updates_all / w.updates_per_step * ncol * args.steps / elapsed if w.updates_per_step else 0.0,
+                          "cells_per_s": updates_all / w.per_cell * args.steps / elapsed},
+               "roofline": roofline_of(w, eng, args, ROOT)}
+        if world == 1 and not args.no_extras and not args.columns:
+            del w
+            torch.cuda.empty_cache()
+            extras = {}
+            for key, (name, ph, st) in {"headline_warm_ph": (args.config, "warm" if args.ph == "cold" else "cold", 5),
+                                        "cfg2": ("cfg2", "cold", 10), "cfg3": ("cfg3", "cold", 5)}.items():
+                if key != "headline_warm_ph" and name == args.config:
+                    continue
+                try:
+                    extras[key] = short_run(eng, torch, L, name, diag_on, ph, st, 2, not args.separate)
+                except Exception as exc:      # never lose the headline over an extra
+                    extras[key] = {"failed": repr(exc)}
+            out["other_workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(nz, modules)

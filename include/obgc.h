@@ -167,6 +167,12 @@ void *obgc_stream(obgc_handle *h);
  * kernel, 2 the ecosystem kernels (PAR scan + cell kernel + particle sweep), 3 layout transposes,
  * 4 the ecosystem cell kernel alone */
 double obgc_last_kernel_ms(obgc_handle *h, int which);
+/* how the last obgc_bgc_source_sink (or obgc_fused_step) arranged its kernels: 0 the carbonate kernel runs from the
+ * start beside the ecosystem kernels, 1 it is released when the cell kernel ends, 2 the carbonate system is solved
+ * inside the cell kernel's wavefronts (one launch for both), 3 the column-block kernel; -1 before the first call.
+ * Every arrangement gives the same bits; the engine picks by batch size (measurement harnesses need to know which
+ * launch `which = 4` of obgc_last_kernel_ms timed). */
+int obgc_last_schedule(obgc_handle *h);
 
 /* --------------------------------------------------------- BGC_SourceSink */
 
@@ -373,21 +379,30 @@ int obgc_accumulate_arrays(obgc_handle *h, const obgc_grid *grid, int nplanes, c
 /* ------------------------------- parameter files and restart state
  * Host-only helpers (no GPU needed).  The reference has no file format: its parameters are module variables.
  * Text format: sections [bgc], [autotroph N], [dms], [macros]; `name = value` with the reference's names; reals
- * are written as C99 hex floats (exact round trip), read as decimal or hex.  Reading only overrides the listed
- * keys, so initialise the structs first (obgc_*_params_init); unknown keys are errors (message in `err`).
- * Any of the three struct pointers may be NULL (section skipped on write, parsed but ignored on read).
- * After editing kSiO3 / *_calcifier / slots call obgc_bgc_params_derive. */
+ * are written as C99 hex floats (exact round trip), read as decimal or hex, always in the "C" locale.  Reading only
+ * overrides the listed keys, so initialise the structs first (obgc_*_params_init); unknown keys are errors (message
+ * in `err`).  Any of the three struct pointers may be NULL (section skipped on write, parsed but ignored on read).
+ * A successful read ends with obgc_bgc_params_derive: the per-autotroph Chl/C/Fe/Si/CaCO3 slots always follow from
+ * kSiO3 / *_calcifier / ind[] as read, whatever *_ind lines the file carries. */
 int obgc_params_write_text(const char *path, const obgc_bgc_params *bgc, const obgc_dms_params *dms,
                            const obgc_macros_params *macros);
 int obgc_params_read_text(const char *path, obgc_bgc_params *bgc, obgc_dms_params *dms, obgc_macros_params *macros,
                           char *err, int errlen);
 /* Restart file of the only state carried between calls: PH_PREV_3D, PH_PREV_ALT_CO2_3D (nlev,ncol) and
- * surface_pH, surface_pH_alt_co2 (ncol), HOST arrays in the reference's order; 64-byte header "OBGCRST1". */
+ * surface_pH, surface_pH_alt_co2 (ncol), HOST arrays in the reference's order; 64-byte header "OBGCRST1" whose
+ * order word (0 = level-fastest, the only one defined) is checked on read. */
 int obgc_restart_write(const char *path, int nlev, int ncol, const double *ph_prev, const double *ph_prev_alt,
                        const double *surface_pH, const double *surface_pH_alt);
 int obgc_restart_read_header(const char *path, int *nlev, int *ncol);
 int obgc_restart_read(const char *path, int nlev, int ncol, double *ph_prev, double *ph_prev_alt, double *surface_pH,
                       double *surface_pH_alt);
+/* The same file for HOST arrays described by a grid struct (either layout, leading dimension grid->ld; memspace must be
+ * OBGC_MEM_HOST): a caller that keeps PH_PREV_* column-fastest -- the engine's native layout -- needs no transpose of
+ * its own.  The file is the same level-fastest file either way. */
+int obgc_restart_write_grid(const char *path, const obgc_grid *grid, const double *ph_prev, const double *ph_prev_alt,
+                            const double *surface_pH, const double *surface_pH_alt);
+int obgc_restart_read_grid(const char *path, const obgc_grid *grid, double *ph_prev, double *ph_prev_alt,
+                           double *surface_pH, double *surface_pH_alt);
 
 /* ------------------------------------------------ column ranges for several devices
  * No statement of the path reads another column (BGC_mod.F90:808-814 resets the only carried scalars), so N
@@ -413,6 +428,20 @@ typedef struct {
   int *kmax;
 } obgc_synth_args;
 int obgc_synth_fill(obgc_handle *h, const obgc_synth_args *a);
+/* The rest of the same workload: the (column) forcing of BGC_SurfaceFluxes / DMS_SurfaceFluxes
+ * (BGC_parms.F90:143-155), the four (column,30) external flux arrays (plane stride ldc) and the own
+ * tracers of DMS (DMS_parms.F90:85-87: dms, dmsp) and MACROS (prot, poly, lip) as (k,column) planes
+ * with level stride ld.  DEVICE pointers; NULL skips a field.  Bit-identical to synth.py. */
+typedef struct {
+  int nlev, ncol;
+  long long col0;
+  long long ld, ldc;
+  double *surfacePressure, *iceFraction, *windSpeedSquared10m, *atmCO2, *atmCO2_ALT_CO2, *surfaceDepth, *SST, *SSS;
+  double *surface_pH, *surface_pH_alt_co2;            /* zero: no previous solution */
+  double *depositionFlux, *riverFlux, *gasFlux, *seaIceFlux;
+  double *dms, *dmsp, *prot, *poly, *lip;
+} obgc_synth_extra_args;
+int obgc_synth_fill_extra(obgc_handle *h, const obgc_synth_extra_args *a);
 
 #ifdef __cplusplus
 }

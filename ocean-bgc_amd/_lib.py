@@ -5,7 +5,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libobgc.so")
+# OBGC_LIB selects another build of the same ABI (the reference-order contract build, `make contract`)
+LIB_PATH = os.environ.get("OBGC_LIB") or os.path.join(_HERE, "libobgc.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 
@@ -140,6 +141,16 @@ class SynthArgs(C.Structure):
                 ("lat", _dptr), ("dust_flux_in", _dptr), ("sw_flux", _dptr), ("kmax", _dptr)]
 
 
+SYNTH_EXTRA_FIELDS = ("surfacePressure", "iceFraction", "windSpeedSquared10m", "atmCO2", "atmCO2_ALT_CO2", "surfaceDepth", "SST",
+                      "SSS", "surface_pH", "surface_pH_alt_co2", "depositionFlux", "riverFlux", "gasFlux", "seaIceFlux",
+                      "dms", "dmsp", "prot", "poly", "lip")
+
+
+class SynthExtraArgs(C.Structure):
+    _fields_ = [("nlev", C.c_int), ("ncol", C.c_int), ("col0", C.c_longlong), ("ld", C.c_longlong), ("ldc", C.c_longlong)] + \
+        [(n, _dptr) for n in SYNTH_EXTRA_FIELDS]
+
+
 # every symbol include/obgc.h declares, with its prototype
 PROTOTYPES = {
     "obgc_abi_version": (C.c_int, []),
@@ -161,6 +172,7 @@ PROTOTYPES = {
     "obgc_set_macros_params": (C.c_int, [C.c_void_p, C.POINTER(MacrosParams)]),
     "obgc_stream": (C.c_void_p, [C.c_void_p]),
     "obgc_last_kernel_ms": (C.c_double, [C.c_void_p, C.c_int]),
+    "obgc_last_schedule": (C.c_int, [C.c_void_p]),
     "obgc_bgc_source_sink": (C.c_int, [C.c_void_p, C.POINTER(BgcSourceSinkArgs)]),
     "obgc_bgc_surface_fluxes": (C.c_int, [C.c_void_p, C.POINTER(BgcSurfaceFluxesArgs)]),
     "obgc_dms_source_sink": (C.c_int, [C.c_void_p, C.POINTER(DmsSourceSinkArgs)]),
@@ -180,10 +192,13 @@ PROTOTYPES = {
     "obgc_partition_columns": (C.c_int, [C.POINTER(C.c_int), C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "obgc_restart_read_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "obgc_restart_read": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dptr, _dptr, _dptr, _dptr]),
+    "obgc_restart_write_grid": (C.c_int, [C.c_char_p, C.POINTER(Grid), _dptr, _dptr, _dptr, _dptr]),
+    "obgc_restart_read_grid": (C.c_int, [C.c_char_p, C.POINTER(Grid), _dptr, _dptr, _dptr, _dptr]),
     "obgc_block_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "obgc_block_destroy": (C.c_int, [C.c_void_p]),
     "obgc_block_step": (C.c_int, [C.c_void_p, C.POINTER(BlockStepArgs)]),
     "obgc_synth_fill": (C.c_int, [C.c_void_p, C.POINTER(SynthArgs)]),
+    "obgc_synth_fill_extra": (C.c_int, [C.c_void_p, C.POINTER(SynthExtraArgs)]),
 }
 
 _lib = None

@@ -13,7 +13,7 @@
 #include <thread>
 #include <vector>
 
-#include "obgc_internal.h"
+#include "obgc_handle.h"
 
 using namespace obgc;
 
@@ -24,49 +24,11 @@ using namespace obgc;
   X(pocToSed) X(SedDenitrif) X(OtherRemin) X(ponToSed) X(popToSed) X(dustToSed) X(pfeToSed) X(DENITRIF) X(O2_CONSUMPTION) \
   X(Fe_scavenge) X(Fe_scavenge_rate)
 
-struct obgc_handle {
-  int device = 0;
-  unsigned flags = 0;
-  hipStream_t s_main = nullptr;   // column-sweep kernels, copies, transposes
-  hipStream_t s_aux = nullptr;    // cell-parallel carbonate kernel runs beside the sweep
-  hipStream_t s_aux2 = nullptr;   // column integrals (diagnostics) run beside both
-  hipStream_t s_up = nullptr, s_down = nullptr;   // host-memory path: uploads / downloads of column chunks (created on first use)
-  int host_chunks = 4;    // OBGC_HOST_CHUNKS: column chunks of the pipelined host-memory path (0 or 1 = stage everything, then run)
-  int host_threads = 1;   // OBGC_HOST_THREADS=0: no helper thread (downloads in line, as when thread creation fails)
-  size_t host_pipeline_min_bytes = (size_t)64 << 20;   // OBGC_HOST_PIPELINE_MIN_MB: smaller calls are staged in one piece
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_e0 = nullptr, ev_e1 = nullptr,
-             ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_aux2_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
-  bool timed_valid = false, tr_valid = false, cell_valid = false;
-  int sweep_lanes = 0;    // experiment knob OBGC_SWEEP_LANES: 16 / 32 / 64 active lanes per wavefront in the sweep, 0 = auto
-  int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
-  int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides
-  int kfast_hybrid = 1;   // OBGC_KFAST_HYBRID=0: transpose every plane (the first implementation) instead of only the column kernels' planes
-  int sched = -1;  // OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel, 2 carbonate inside the cell kernel's
-                   // wavefronts, -1 (default) = 1, or for batches of more than 10 M cells 2 with diagnostics and 0 without (see bgc_launch)
-  obgc_bgc_params bgc;
-  obgc_dms_params dms;
-  obgc_macros_params macros;
-  // device scratch: one growing arena, carved per call
-  char* arena = nullptr;
-  size_t arena_bytes = 0, arena_used = 0;
-  std::string err;
-};
 
 namespace {
 
 constexpr double kDps = 1.0 / 86400.0;
 
-int fail(obgc_handle* h, int code, const std::string& msg) {
-  if (h) h->err = msg;
-  return code;
-}
-
-#define HIP_TRY(h, call)                                                                         \
-  do {                                                                                           \
-    hipError_t e_ = (call);                                                                      \
-    if (e_ != hipSuccess)                                                                        \
-      return fail(h, OBGC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
-  } while (0)
 
 // ---- scratch arena ---------------------------------------------------------------------
 int arena_reserve(obgc_handle* h, size_t bytes) {
@@ -214,6 +176,8 @@ int finish(obgc_handle* h, bool force_sync) {
 }
 
 }  // namespace
+
+int obgc::handle_device(const obgc_handle* h) { return h->device; }
 
 // ============================================================================ parameters ==
 
@@ -400,6 +364,8 @@ extern "C" int obgc_set_macros_params(obgc_handle* h, const obgc_macros_params* 
   return OBGC_OK;
 }
 
+extern "C" int obgc_last_schedule(obgc_handle* h) { return h ? h->last_sched : -1; }
+
 extern "C" double obgc_last_kernel_ms(obgc_handle* h, int which) {
   if (!h || !h->timed_valid) return -1.0;
   if (hipEventSynchronize(h->ev_end) != hipSuccess) return -1.0;
@@ -481,6 +447,7 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   // Without diagnostics the large batches do best with the carbonate kernel started first (-4 % at 1 M columns, nothing at 100 k).
   const bool large = (long long)K.g.nlev * K.g.ncol > 10000000LL;
   const int sched = h->sched >= 0 ? h->sched : (large ? (K.have_diag ? 2 : 0) : 1);
+  h->last_sched = sched;
   HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
   launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1, sched == 2);
   h->cell_valid = true;
@@ -566,6 +533,7 @@ int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, b
     launch_bgc_cell(Kt, P, h->s_main, 0);
     HIP_TRY(h, hipEventRecord(h->ev_k1, h->s_main));
     h->cell_valid = true;
+    h->last_sched = 1;
     // hand-off of the cell kernel: production terms, parked tendencies (+ DIC_ALT_CO2's plane, whose zero fill must
     // survive), with diagnostics the local integrands and the four production profiles
     PlaneTable th; th.n = 0;
@@ -1334,6 +1302,16 @@ extern "C" int obgc_synth_fill(obgc_handle* h, const obgc_synth_args* a) {
   if (!h || !a || a->nlev < 1 || a->ncol < 0) return OBGC_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   launch_synth(*a, a->ind, h->s_main);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->s_main));
+  return OBGC_OK;
+}
+
+extern "C" int obgc_synth_fill_extra(obgc_handle* h, const obgc_synth_extra_args* a) {
+  if (!h || !a || a->nlev < 1 || a->ncol < 0) return OBGC_ERR_INVALID;
+  if ((a->ld != 0 && a->ld < a->ncol) || (a->ldc != 0 && a->ldc < a->ncol)) return fail(h, OBGC_ERR_INVALID, "bad leading dimension");
+  HIP_TRY(h, hipSetDevice(h->device));
+  launch_synth_extra(*a, h->s_main);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->s_main));
   return OBGC_OK;

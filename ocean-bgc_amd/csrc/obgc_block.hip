@@ -130,6 +130,7 @@ using namespace obgc;
 
 extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, obgc_block** out) {
   if (!h || !out || nCells < 1 || nVertLevels < 1) return OBGC_ERR_INVALID;
+  if (hipSetDevice(handle_device(h)) != hipSuccess) return OBGC_ERR_HIP;   // the pool and s_down belong to the handle's GPU
   obgc_block* b = new obgc_block;
   b->h = h;
   b->nc = nCells;
@@ -157,10 +158,10 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
   for (auto& s : slots) *s.first = b->pool + s.second;
   hipStream_t st = (hipStream_t)obgc_stream(h);
   // no previous pH anywhere, no gas flux before the first call
-  (void)hipMemsetAsync(b->php, 0, kc * d, st); (void)hipMemsetAsync(b->pha, 0, kc * d, st);
-  (void)hipMemsetAsync(b->sph, 0, nc * d, st); (void)hipMemsetAsync(b->spha, 0, nc * d, st);
-  (void)hipMemsetAsync(b->gas, 0, NT * nc * d, st);
-  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(b->pool); delete b; return OBGC_ERR_HIP; }
+  bool zeroed = hipMemsetAsync(b->php, 0, kc * d, st) == hipSuccess && hipMemsetAsync(b->pha, 0, kc * d, st) == hipSuccess &&
+                hipMemsetAsync(b->sph, 0, nc * d, st) == hipSuccess && hipMemsetAsync(b->spha, 0, nc * d, st) == hipSuccess &&
+                hipMemsetAsync(b->gas, 0, NT * nc * d, st) == hipSuccess;
+  if (!zeroed || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(b->pool); delete b; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_BLOCK_CHUNKS")) b->chunks = std::atoi(e);
   if (const char* e = std::getenv("OBGC_HOST_THREADS")) b->threads = std::atoi(e);
   if (const char* e = std::getenv("OBGC_BLOCK_MIN_CELLS")) b->min_cells = std::atoi(e);
@@ -175,6 +176,7 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
 
 extern "C" int obgc_block_destroy(obgc_block* b) {
   if (!b) return OBGC_ERR_INVALID;
+  (void)hipSetDevice(handle_device(b->h));
   (void)obgc_sync(b->h);
   if (b->s_down) (void)hipStreamDestroy(b->s_down);
   for (hipEvent_t e : b->ev_done) if (e) (void)hipEventDestroy(e);
@@ -269,6 +271,8 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
     return OBGC_ERR_INVALID;
   const int nc = b->nc;
   const size_t d = sizeof(double);
+  const int device = handle_device(b->h);
+  if (hipSetDevice(device) != hipSuccess) return OBGC_ERR_HIP;   // the calling thread's current device may be another GPU
   hipStream_t st = (hipStream_t)obgc_stream(b->h);
   // per-cell arrays: small, whole block at once
 #define UP(dst, src, bytes) if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return OBGC_ERR_HIP;
@@ -295,8 +299,6 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   int ready = 0;
   bool stop = false;
   hipError_t down_err = hipSuccess;
-  int device = 0;
-  (void)hipGetDevice(&device);
   std::thread downloader;
   bool threaded = b->threads != 0;
   try {

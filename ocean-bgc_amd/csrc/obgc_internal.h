@@ -119,6 +119,7 @@ void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s)
 void launch_dms_surface(const DmsSurfKernelArgs& a, const obgc_dms_params& p, hipStream_t s);
 void launch_macros(const MacrosKernelArgs& a, const obgc_macros_params& p, hipStream_t s);
 void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s);
+void launch_synth_extra(const obgc_synth_extra_args& a, hipStream_t s);
 // (source, destination) pairs of obgc_bgc_diag_accumulate: first `nplane` (k,column) planes, then `nvec` (column) vectors
 struct AccumTable {
   enum { kMax = 176 };
@@ -150,6 +151,9 @@ void launch_transpose_table_c2k(const PlaneTable& t, int nlev, int ncol, long lo
 void launch_bgc_att(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_parscan(const BgcKernelArgs& a, hipStream_t s);
 void launch_bgc_cell(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int fuse_carbonate);
+
+// device ordinal a handle was created on (obgc_api.hip owns the handle's definition)
+int handle_device(const obgc_handle* h);
 
 // ---------------------------------------------------------------- small device helpers
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }

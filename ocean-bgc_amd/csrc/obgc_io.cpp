@@ -5,19 +5,26 @@
 //
 // Parameter file: UTF-8 text, '#' comments, sections [bgc], [autotroph N] (N = 1..4), [dms], [macros]; one
 // `name = value` per line; names are the reference's (include/obgc_fields.h).  Reals are written as C99 hex floats
-// (exact round trip) and read with strtod (decimal or hex).  A file only overrides the keys it lists: the structs
-// must hold defaults (obgc_*_params_init) before reading.  Unknown keys or sections are errors, not warnings.
+// (exact round trip) and read as decimal or hex, both in the "C" locale whatever the process locale is.  A file only
+// overrides the keys it lists: the structs must hold defaults (obgc_*_params_init) before reading.  Unknown keys or
+// sections are errors, not warnings.  The per-autotroph tracer slots (Chl_ind, C_ind, Fe_ind, Si_ind, CaCO3_ind) are
+// derived quantities (BGC_mod.F90:271-321): they are written for the reader's information and re-derived after a read.
 //
 // Restart file: little-endian binary, 64-byte header
-//   char magic[8] = "OBGCRST1"; int32 nlev, ncol; int32 reserved[12];
-// followed by four fp64 arrays in the reference's order: PH_PREV_3D(nlev,ncol), PH_PREV_ALT_CO2_3D(nlev,ncol),
-// surface_pH(ncol), surface_pH_alt_co2(ncol).
+//   char magic[8] = "OBGCRST1"; int32 nlev, ncol; int32 order; int32 reserved[11];
+// followed by four dense fp64 arrays: PH_PREV_3D(nlev,ncol), PH_PREV_ALT_CO2_3D(nlev,ncol), surface_pH(ncol),
+// surface_pH_alt_co2(ncol).  `order` = 0: level-fastest, the reference's X(k,column) -- the only order ever written; any
+// other value is rejected on read.  Callers that hold the state column-fastest (the engine's native layout) use the
+// *_grid variants, which convert while writing / reading.
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <locale.h>
 #include <string>
+#include <vector>
 
 #include "obgc.h"
 
@@ -32,11 +39,26 @@ std::string trim(const std::string& s) {
   return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
 }
 
+// the "C" locale, whatever the host program has set: a decimal comma must neither be written nor expected
+locale_t c_locale() {
+  static locale_t loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+  return loc;
+}
+
 bool parse_real(const std::string& v, double& out) {
   errno = 0;
   char* end = nullptr;
-  out = std::strtod(v.c_str(), &end);
+  out = strtod_l(v.c_str(), &end, c_locale());
   return end != v.c_str() && *end == '\0' && errno == 0;
+}
+
+// "%a" of a double with a '.' as the radix character in every locale
+std::string hexfloat(double x) {
+  char buf[64];
+  locale_t old = uselocale(c_locale());
+  std::snprintf(buf, sizeof buf, "%a", x);
+  uselocale(old);
+  return buf;
 }
 
 bool parse_int(const std::string& v, int& out) {
@@ -86,7 +108,8 @@ bool set_macros(obgc_macros_params* p, const std::string& k, const std::string& 
 struct RestartHeader {
   char magic[8];
   int32_t nlev, ncol;
-  int32_t reserved[12];
+  int32_t order;          // 0 = level-fastest X(k,column); nothing else is defined
+  int32_t reserved[11];
 };
 static_assert(sizeof(RestartHeader) == 64, "restart header is 64 bytes");
 const char kMagic[8] = {'O', 'B', 'G', 'C', 'R', 'S', 'T', '1'};
@@ -101,31 +124,31 @@ extern "C" int obgc_params_write_text(const char* path, const obgc_bgc_params* b
   std::fprintf(f, "# obgc parameters v1 -- names as in the reference's *_parms modules; reals as C99 hex floats\n");
   if (bgc) {
     std::fprintf(f, "[bgc]\n");
-#define X(n) std::fprintf(f, "%s = %a\n", #n, bgc->n);
+#define X(n) std::fprintf(f, "%s = %s\n", #n, hexfloat(bgc->n).c_str());
     OBGC_BGC_PARMS(X)
 #undef X
-    std::fprintf(f, "T0_Kelvin_BGC = %a\n", bgc->T0_Kelvin_BGC);
-    for (int i = 0; i < 4; ++i) std::fprintf(f, "parm_scalelen_z(%d) = %a\n", i + 1, bgc->parm_scalelen_z[i]);
-    for (int i = 0; i < 4; ++i) std::fprintf(f, "parm_scalelen_vals(%d) = %a\n", i + 1, bgc->parm_scalelen_vals[i]);
+    std::fprintf(f, "T0_Kelvin_BGC = %s\n", hexfloat(bgc->T0_Kelvin_BGC).c_str());
+    for (int i = 0; i < 4; ++i) std::fprintf(f, "parm_scalelen_z(%d) = %s\n", i + 1, hexfloat(bgc->parm_scalelen_z[i]).c_str());
+    for (int i = 0; i < 4; ++i) std::fprintf(f, "parm_scalelen_vals(%d) = %s\n", i + 1, hexfloat(bgc->parm_scalelen_vals[i]).c_str());
     for (int a = 0; a < OBGC_AUTOTROPH_CNT; ++a) {
       std::fprintf(f, "[autotroph %d]\n", a + 1);
 #define X(n) std::fprintf(f, "%s = %d\n", #n, bgc->autotrophs[a].n);
       OBGC_AUTOTROPH_INTS(X)
 #undef X
-#define X(n) std::fprintf(f, "%s = %a\n", #n, bgc->autotrophs[a].n);
+#define X(n) std::fprintf(f, "%s = %s\n", #n, hexfloat(bgc->autotrophs[a].n).c_str());
       OBGC_AUTOTROPH_REALS(X)
 #undef X
     }
   }
   if (dms) {
     std::fprintf(f, "[dms]\n");
-#define X(n) std::fprintf(f, "%s = %a\n", #n, dms->n);
+#define X(n) std::fprintf(f, "%s = %s\n", #n, hexfloat(dms->n).c_str());
     OBGC_DMS_PARMS(X)
 #undef X
   }
   if (macros) {
     std::fprintf(f, "[macros]\n");
-#define X(n) std::fprintf(f, "%s = %a\n", #n, macros->n);
+#define X(n) std::fprintf(f, "%s = %s\n", #n, hexfloat(macros->n).c_str());
     OBGC_MACROS_PARMS(X)
 #undef X
   }
@@ -135,15 +158,14 @@ extern "C" int obgc_params_write_text(const char* path, const obgc_bgc_params* b
 extern "C" int obgc_params_read_text(const char* path, obgc_bgc_params* bgc, obgc_dms_params* dms, obgc_macros_params* macros,
                                      char* err, int errlen) {
   if (!path) return OBGC_ERR_INVALID;
-  FILE* f = std::fopen(path, "r");
+  std::ifstream f(path);
   if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return OBGC_ERR_INVALID; }
   enum { NONE, BGC, AUTO, DMS, MACROS } sec = NONE;
   int autotroph = 0, lineno = 0;
-  char buf[512];
   int rc = OBGC_OK;
-  while (rc == OBGC_OK && std::fgets(buf, sizeof buf, f)) {
+  std::string line;
+  while (rc == OBGC_OK && std::getline(f, line)) {   // whole lines of any length
     ++lineno;
-    std::string line(buf);
     const size_t hash = line.find('#');
     if (hash != std::string::npos) line.erase(hash);
     line = trim(line);
@@ -176,7 +198,9 @@ extern "C" int obgc_params_read_text(const char* path, obgc_bgc_params* bgc, obg
     }
     if (!ok) bad("unknown key or malformed value: " + k + " = " + v);
   }
-  std::fclose(f);
+  // kSiO3, imp_calcifier / exp_calcifier decide which autotroph owns a Si / CaCO3 pool (BGC_mod.F90:303-320): the
+  // slots the kernels branch on always follow from the table just read, never from a stale *_ind line of the file
+  if (rc == OBGC_OK && bgc) obgc_bgc_params_derive(bgc);
   return rc;
 }
 
@@ -204,7 +228,8 @@ extern "C" int obgc_restart_read_header(const char* path, int* nlev, int* ncol) 
   FILE* f = std::fopen(path, "rb");
   if (!f) return OBGC_ERR_INVALID;
   RestartHeader h;
-  const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, kMagic, 8) == 0 && h.nlev >= 1 && h.ncol >= 0;
+  const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, kMagic, 8) == 0 && h.nlev >= 1 && h.ncol >= 0 &&
+                  h.order == 0;
   std::fclose(f);
   if (!ok) return OBGC_ERR_INVALID;
   *nlev = h.nlev;
@@ -228,6 +253,51 @@ extern "C" int obgc_restart_read(const char* path, int nlev, int ncol, double* p
   ok = ok && std::fgetc(f) == EOF;
   std::fclose(f);
   return ok ? OBGC_OK : OBGC_ERR_INVALID;
+}
+
+namespace {
+
+// (k,column) element of a host array described by an obgc_grid
+inline size_t grid_at(const obgc_grid& g, int k, int c) {
+  if (g.layout == OBGC_LAYOUT_KFAST) return (size_t)c * (size_t)(g.ld > 0 ? g.ld : g.nlev) + (size_t)k;
+  return (size_t)k * (size_t)(g.ld > 0 ? g.ld : g.ncol) + (size_t)c;
+}
+
+bool grid_host_ok(const obgc_grid* g) {
+  if (!g || g->nlev < 1 || g->ncol < 0 || g->memspace != OBGC_MEM_HOST) return false;
+  if (g->layout != OBGC_LAYOUT_KFAST && g->layout != OBGC_LAYOUT_COLFAST) return false;
+  const long long minld = g->layout == OBGC_LAYOUT_KFAST ? g->nlev : g->ncol;
+  return g->ld == 0 || g->ld >= minld;
+}
+
+}  // namespace
+
+extern "C" int obgc_restart_write_grid(const char* path, const obgc_grid* g, const double* ph_prev, const double* ph_prev_alt,
+                                       const double* surface_pH, const double* surface_pH_alt) {
+  if (!grid_host_ok(g) || (g->ncol > 0 && (!ph_prev || !ph_prev_alt))) return OBGC_ERR_INVALID;
+  const size_t n3 = (size_t)g->nlev * (size_t)g->ncol;
+  std::vector<double> a(n3), b(n3);
+  for (int c = 0; c < g->ncol; ++c)
+    for (int k = 0; k < g->nlev; ++k) {
+      a[(size_t)c * g->nlev + k] = ph_prev[grid_at(*g, k, c)];
+      b[(size_t)c * g->nlev + k] = ph_prev_alt[grid_at(*g, k, c)];
+    }
+  return obgc_restart_write(path, g->nlev, g->ncol, a.data(), b.data(), surface_pH, surface_pH_alt);
+}
+
+extern "C" int obgc_restart_read_grid(const char* path, const obgc_grid* g, double* ph_prev, double* ph_prev_alt, double* surface_pH,
+                                      double* surface_pH_alt) {
+  if (!grid_host_ok(g) || (g->ncol > 0 && (!ph_prev || !ph_prev_alt))) return OBGC_ERR_INVALID;
+  const size_t n3 = (size_t)g->nlev * (size_t)g->ncol;
+  std::vector<double> a(n3), b(n3);
+  const int rc = obgc_restart_read(path, g->nlev, g->ncol, a.data(), b.data(), surface_pH, surface_pH_alt);
+  if (rc != OBGC_OK) return rc;
+  for (int c = 0; c < g->ncol; ++c)
+    for (int k = 0; k < g->nlev; ++k) {
+      ph_prev[grid_at(*g, k, c)] = a[(size_t)c * g->nlev + k];
+      ph_prev_alt[grid_at(*g, k, c)] = b[(size_t)c * g->nlev + k];
+    }
+  return OBGC_OK;
 }
 
 // Static contiguous column ranges for `nparts` devices.  Columns are independent, so any cut is

@@ -121,7 +121,72 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthArgs S) {
   for (int n = 0; n < 30; ++n) a.tracers[(long long)(S.ind[n] - 1) * a.plane + ix] = t[n];
 }
 
+// The rest of the workload: the surface forcing of BGC_SurfaceFluxes / DMS_SurfaceFluxes (BGC_parms.F90:143-155), the four
+// external flux arrays and the own tracers of DMS and MACROS -- same closed forms as synth.py.
+__global__ __launch_bounds__(256) void synth_extra_kernel(const obgc_synth_extra_args a) {
+  const long long ncell = (long long)a.nlev * a.ncol;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncell) return;
+  const int cl = (int)(idx % a.ncol), k = (int)(idx / a.ncol);
+  const unsigned long long c = (unsigned long long)(a.col0 + cl);
+  const long long ix = (long long)k * a.ld + cl;
+  const double kf = (double)k;
+  const double dz = 1000.0 * (1.0 + 0.05 * kf);
+  const double zbot = 1000.0 * ((kf + 1.0) + 0.025 * (kf * (kf + 1.0)));
+  const double zmid = zbot - 0.5 * dz;
+  const double s = zmid / (zmid + 3.0e4);
+  const double q = 1.0 / (1.0 + zmid / 8.0e3);
+  const double e = q * q;
+  if (a.dms) a.dms[ix] = (2.0e-3 * e) * (0.5 + ucol(c, 50)) + 1.0e-5;
+  if (a.dmsp) a.dmsp[ix] = (5.0e-3 * e) * (0.5 + ucol(c, 51)) + 1.0e-5;
+  if (a.prot) a.prot[ix] = 1.0 * (0.5 + ucol(c, 52)) + 0.0 * s;
+  if (a.poly) a.poly[ix] = 2.0 * (0.5 + ucol(c, 53)) + 0.0 * s;
+  if (a.lip) a.lip[ix] = 0.1 * (0.5 + ucol(c, 54)) + 0.0 * s;
+  if (k != 0) return;
+  if (a.surfacePressure) a.surfacePressure[cl] = 0.98 + 0.04 * ucol(c, 40);
+  const double u41 = ucol(c, 41);
+  if (a.iceFraction) a.iceFraction[cl] = (u41 < 0.005) ? -0.1 : ((u41 > 0.995) ? 1.2 : 0.3 * u41);
+  const double w = (3.0 + 12.0 * ucol(c, 42)) * 100.0;
+  if (a.windSpeedSquared10m) a.windSpeedSquared10m[cl] = w * w;
+  if (a.atmCO2) a.atmCO2[cl] = 400.0;
+  if (a.atmCO2_ALT_CO2) a.atmCO2_ALT_CO2[cl] = 280.0;
+  if (a.surface_pH) a.surface_pH[cl] = 0.0;
+  if (a.surface_pH_alt_co2) a.surface_pH_alt_co2[cl] = 0.0;
+  if (a.surfaceDepth) a.surfaceDepth[cl] = 1000.0 / 200.0;      // dz(1) / 200
+  const double r = 1.0 / (1.0 + zmid / 4.0e4);
+  const double u1 = ucol(c, 1);
+  if (a.SST) a.SST[cl] = -1.8 + (4.0 + 26.0 * (u1 * u1)) * r;
+  if (a.SSS) a.SSS[cl] = 33.0 + 3.0 * ucol(c, 2);
+}
+
+__global__ __launch_bounds__(256) void synth_flux_kernel(const obgc_synth_extra_args a) {
+  const long long n30 = 30LL * a.ncol;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n30) return;
+  const int cl = (int)(idx % a.ncol), n = (int)(idx / a.ncol);
+  const unsigned long long c = (unsigned long long)(a.col0 + cl);
+  const long long ix = (long long)n * a.ldc + cl;
+  if (a.depositionFlux) a.depositionFlux[ix] = 1.0e-9 * ucell(c, (unsigned long long)n, 1);
+  if (a.riverFlux) a.riverFlux[ix] = 1.0e-9 * ucell(c, (unsigned long long)n, 2);
+  if (a.gasFlux) a.gasFlux[ix] = 1.0e-9 * ucell(c, (unsigned long long)n, 3);
+  if (a.seaIceFlux) a.seaIceFlux[ix] = 1.0e-9 * ucell(c, (unsigned long long)n, 4);
+}
+
 }  // namespace
+
+void launch_synth_extra(const obgc_synth_extra_args& a0, hipStream_t s) {
+  obgc_synth_extra_args a = a0;
+  if (a.ld <= 0) a.ld = a.ncol;
+  if (a.ldc <= 0) a.ldc = a.ncol;
+  const long long ncell = (long long)a.nlev * a.ncol;
+  if (ncell <= 0) return;
+  const bool planes = a.dms || a.dmsp || a.prot || a.poly || a.lip;
+  if (!planes) a.nlev = 1;      // only level 0 writes the per-column fields
+  const long long n1 = (long long)a.nlev * a.ncol;
+  hipLaunchKernelGGL(synth_extra_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, a);
+  if (a.depositionFlux || a.riverFlux || a.gasFlux || a.seaIceFlux)
+    hipLaunchKernelGGL(synth_flux_kernel, dim3((unsigned)((30LL * a.ncol + 255) / 256)), dim3(256), 0, s, a);
+}
 
 void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s) {
   SynthArgs S;

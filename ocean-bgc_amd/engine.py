@@ -122,6 +122,9 @@ class Engine:
     def last_kernel_ms(self, which=0):
         return self.lib.obgc_last_kernel_ms(self.h, which)
 
+    def last_schedule(self):
+        return self.lib.obgc_last_schedule(self.h)
+
     # ---- helpers ------------------------------------------------------------------------
     @staticmethod
     def _fill(struct, names, arrays, memspace):
@@ -300,3 +303,18 @@ class Engine:
                 raise ObgcError("synth_fill needs device tensors")
             setattr(a, nm, p)
         self._check(self.lib.obgc_synth_fill(self.h, C.byref(a)), "obgc_synth_fill")
+
+    def synth_fill_extra(self, nlev, ncol, col0, ld=0, ldc=0, **dev_arrays):
+        """Surface forcing, external fluxes and the DMS / MACROS own tracers of the synthetic workload (device tensors)."""
+        a = L.SynthExtraArgs()
+        a.nlev, a.ncol, a.col0, a.ld, a.ldc = nlev, ncol, col0, ld, ldc
+        for nm, x in dev_arrays.items():
+            if nm not in L.SYNTH_EXTRA_FIELDS:
+                raise ObgcError("synth_fill_extra: unknown field %s" % nm)
+            if x is None:
+                continue
+            p, dev = _ptr(x)
+            if not dev:
+                raise ObgcError("synth_fill_extra needs device tensors")
+            setattr(a, nm, p)
+        self._check(self.lib.obgc_synth_fill_extra(self.h, C.byref(a)), "obgc_synth_fill_extra")

@@ -11,6 +11,9 @@ branch-coverage columns and every output array the reference produced for them.
   config1_1x60.npz       BASELINE config #1: 1 column x 60 levels, every module
   branch_cols_60.npz     24 columns x 60 levels chosen to hit the branches of SURVEY 8d
   branch_cols_100.npz    8 columns x 100 levels (crosses 3300 m lysocline test, BGC_mod.F90:2564)
+  branch_cols_80.npz     12 columns x 80 levels: the level count of BASELINE config #4 (BGC + DMS + MACROS)
+
+    python tests/golden/make_golden.py [tag ...]      only the named fixtures (default: all)
   kat.npz                known-answer values: O2SAT(10 C, 35 psu) (BGC_mod.F90:3028-3029),
                          Schmidt numbers, carbonate terms on a small (T,S,depth) grid
 """
@@ -197,14 +200,19 @@ def kat(R):
 def main():
     assert refbind.available(), "build the reference first: make -C oracle ref"
     R = refbind.Ref()
-    run_all(R, gather(60, [0]), "config1_1x60")
-    cols = pick_columns(60, 24)
-    print("branch columns (nz=60):", cols)
-    run_all(R, gather(60, cols), "branch_cols_60")
-    cols = pick_columns(100, 8)
-    print("branch columns (nz=100):", cols)
-    run_all(R, gather(100, cols), "branch_cols_100")
-    kat(R)
+    only = set(sys.argv[1:])
+    want = lambda tag: not only or tag in only
+    if want("config1_1x60"):
+        run_all(R, gather(60, [0]), "config1_1x60")
+    for tag, nz, n in (("branch_cols_60", 60, 24), ("branch_cols_100", 100, 8), ("branch_cols_80", 80, 12)):
+        if want(tag):
+            cols = pick_columns(nz, n)
+            print("branch columns (nz=%d):" % nz, cols)
+            run_all(R, gather(nz, cols), tag)
+    if want("kat"):
+        kat(R)
+    if only and "params" not in only:
+        return
     # parameter tables + names (pins *_parms_init / *_init)
     p = R.bgc_get_params()
     names = R.bgc_names()

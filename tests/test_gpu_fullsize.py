@@ -112,11 +112,32 @@ def test_cfg2_100k_x_60_properties(gpu, oracle, synth):
     assert rep.ok(), "\n".join(rep.fail[:8])
 
 
-def test_cfg3_1M_x_60_tendencies_only(gpu):
-    """1M columns: no diagnostics (62 GB of them would fit, but the property is size, not content)."""
+def make_surface(torch, L, eng, nz, nc, col0):
+    f64 = dict(dtype=torch.float64, device="cuda")
+    s = dict(forcing={nm: torch.empty((nc,), **f64) for nm in ("surfacePressure", "iceFraction", "windSpeedSquared10m", "atmCO2",
+                                                               "atmCO2_ALT_CO2", "surfaceDepth", "SST", "SSS", "surface_pH",
+                                                               "surface_pH_alt_co2")},
+             flux={nm: torch.empty((30, nc), **f64) for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")},
+             net=torch.full((30, nc), -7.0, **f64), diag={nm: torch.full((nc,), -7.0, **f64) for nm in L.BGC_FLUX_DIAG})
+    eng.synth_fill_extra(nz, nc, col0, **s["forcing"], **s["flux"])
+    torch.cuda.synchronize()
+    return s
+
+
+def run_surface(L, eng, b, s):
+    eng.bgc_surface_fluxes(b["nz"], b["nc"], L.OBGC_LAYOUT_COLFAST, b["tr"], s["forcing"],
+                           *[s["flux"][nm] for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")], s["net"], s["diag"])
+
+
+def test_cfg3_1M_x_60_surface_fluxes_and_tendencies(gpu, oracle, synth):
+    """BASELINE config #3 at full size: BGC_SurfaceFluxes + BGC_SourceSink over 1M columns (no interior diagnostics:
+    62 GB of them would fit, but the property is size, not content)."""
     torch, L, eng = gpu
     nz, nc = 60, 1_000_000
     b = make_batch(torch, L, eng, nz, nc, 0, diag=False)
+    sf = make_surface(torch, L, eng, nz, nc, 0)
+    ice_in = sf["forcing"]["iceFraction"].clone()
+    run_surface(L, eng, b, sf)
     run(L, eng, b)
     assert torch.isfinite(b["tend"]).all()
     k = torch.arange(nz, device="cuda")[:, None]
@@ -126,6 +147,31 @@ def test_cfg3_1M_x_60_tendencies_only(gpu):
     s = make_batch(torch, L, eng, nz, wn, w0, diag=False)
     run(L, eng, s)
     assert torch.equal(s["tend"], b["tend"][:, :, w0:w0 + wn]) and torch.equal(s["ph"], b["ph"][:, :, w0:w0 + wn])
+    # ---- the surface call at 1M columns: finite, in-place clamp, a window on its own, an oracle sample ----
+    assert torch.isfinite(sf["net"]).all() and all(torch.isfinite(v).all() for v in sf["diag"].values())
+    assert torch.equal(sf["forcing"]["iceFraction"], ice_in.clamp(0.0, 1.0)) and (ice_in < 0).any() and (ice_in > 1).any()
+    ph = sf["forcing"]["surface_pH"]
+    assert float(ph.min()) > 4.0 and float(ph.max()) < 10.0          # land columns included: the reference solves them too
+    ss = make_surface(torch, L, eng, nz, wn, w0)
+    run_surface(L, eng, s, ss)
+    assert torch.equal(ss["net"], sf["net"][:, w0:w0 + wn]) and torch.equal(ss["forcing"]["surface_pH"], ph[w0:w0 + wn])
+    for nm, v in ss["diag"].items():
+        assert torch.equal(v, sf["diag"][nm][w0:w0 + wn]), nm
+    cols = np.arange(0, nc, 1999)
+    syn_cols = [synth.generate(1, nz, col0=int(c)) for c in cols[:64]]
+    for j, sy in enumerate(syn_cols[:8]):                              # device inputs are the numpy generator's, bit for bit
+        assert np.array_equal(b["tr"][:, :, int(cols[j])].cpu().numpy(), synth.bgc_tracer_array(sy)[:, 0, :])
+    tr_h = np.concatenate([synth.bgc_tracer_array(sy) for sy in syn_cols], axis=1)
+    f_h = {nm: np.concatenate([sy["forcing"][nm] for sy in syn_cols]) for nm in syn_cols[0]["forcing"]}
+    flux_h = [np.concatenate([sy[nm] for sy in syn_cols], axis=1) for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")]
+    want = oracle.bgc_surface_fluxes(tr_h, f_h, *flux_h)
+    sel = torch.as_tensor(cols[:64], device="cuda")
+    got = dict(forcing={nm: v[sel].cpu().numpy() for nm, v in sf["forcing"].items()}, netFlux=sf["net"][:, sel].cpu().numpy(),
+               fdiag={nm: v[sel].cpu().numpy() for nm, v in sf["diag"].items()})
+    for nm, a in (("depositionFlux", 0), ("riverFlux", 1), ("gasFlux", 2), ("seaIceFlux", 3)):
+        got[nm] = sf["flux"][nm][:, sel].cpu().numpy()
+    rep = P.compare_surface(got, want)
+    assert rep.ok(), "\n".join(rep.fail[:8])
 
 
 def test_large_batch_with_diagnostics_takes_the_fused_schedule(gpu):

@@ -38,7 +38,7 @@ def bgc_common(g):
 
 
 @pytest.mark.parametrize("path", PATHS)
-@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_100"])
+@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_80", "branch_cols_100"])
 def test_bgc_source_sink_vs_reference_golden(engines, path, fixture):
     E = engines[path]
     g = load(fixture)
@@ -83,7 +83,7 @@ def test_bgc_surface_fluxes_vs_reference_golden(engines, path):
 
 
 @pytest.mark.parametrize("path", PATHS)
-@pytest.mark.parametrize("fixture", ["branch_cols_60", "branch_cols_100"])
+@pytest.mark.parametrize("fixture", ["branch_cols_60", "branch_cols_80", "branch_cols_100"])
 def test_dms_macros_vs_reference_golden(engines, path, fixture):
     E = engines[path]
     g = load(fixture)

@@ -33,7 +33,7 @@ def forcing_of(g, prefix):
     return {nm: g["%s.%s" % (prefix, nm)] for nm in F.BGC_SURF_FORCING}
 
 
-@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_100"])
+@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_80", "branch_cols_100"])
 def test_bgc_source_sink_matches_golden(oracle, fixture):
     g = load(fixture)
     nc, nz = g["in.temp"].shape
@@ -76,7 +76,7 @@ def test_bgc_surface_fluxes_matches_golden(oracle, fixture):
     assert s1["forcing"]["iceFraction"].min() >= 0.0 and s1["forcing"]["iceFraction"].max() <= 1.0
 
 
-@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_100"])
+@pytest.mark.parametrize("fixture", ["config1_1x60", "branch_cols_60", "branch_cols_80", "branch_cols_100"])
 def test_dms_macros_match_golden(oracle, fixture):
     g = load(fixture)
     f = forcing_of(g, "in.forcing")

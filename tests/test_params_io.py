@@ -79,3 +79,80 @@ def test_restart_file_round_trip_and_validation(L, tmp_path):
     with open(path, "r+b") as f:
         f.write(b"NOTOBGC1")
     assert lib.obgc_restart_read_header(path, C.byref(fl), C.byref(fc)) == -1        # bad magic
+
+
+def test_read_rederives_the_autotroph_slots_and_ignores_stale_ind_lines(L, tmp_path):
+    """kSiO3 / imp_calcifier decide which autotroph owns a Si / CaCO3 pool (BGC_mod.F90:303-320): after a read the slots
+    the kernels branch on follow from the table read, not from *_ind lines of the file."""
+    lib, b, d, m = _defaults(L)
+    assert b.autotrophs[1].Si_ind == 24 and b.autotrophs[0].Si_ind == 0 and b.autotrophs[0].CaCO3_ind == 20
+    p = tmp_path / "si.txt"
+    # small phytoplankton become silicifiers, diatoms stop; the file also carries a stale, contradicting Si_ind line
+    p.write_text("[autotroph 1]\nkSiO3 = 0.5\nimp_calcifier = 0\nSi_ind = 0\n[autotroph 2]\nkSiO3 = 0.0\nSi_ind = 24\nCaCO3_ind = 20\n")
+    err = C.create_string_buffer(256)
+    assert lib.obgc_params_read_text(str(p).encode(), C.byref(b), None, None, err, 256) == 0, err.value
+    assert b.autotrophs[0].Si_ind == 24 and b.autotrophs[1].Si_ind == 0
+    assert b.autotrophs[0].CaCO3_ind == 0 and b.autotrophs[1].CaCO3_ind == 0
+
+
+def test_long_lines_and_decimal_comma_locales(L, tmp_path):
+    lib, b, d, m = _defaults(L)
+    p = tmp_path / "long.txt"
+    p.write_text("[bgc]\nparm_o2_min = 3.5   #" + "x" * 5000 + "\nparm_o2_min_delta = 2.25\n")
+    err = C.create_string_buffer(256)
+    assert lib.obgc_params_read_text(str(p).encode(), C.byref(b), None, None, err, 256) == 0, err.value
+    assert b.parm_o2_min == 3.5 and b.parm_o2_min_delta == 2.25
+    # a process locale with a decimal comma must neither be written nor expected
+    import locale
+    old = locale.setlocale(locale.LC_NUMERIC)
+    try:
+        for cand in ("de_DE.UTF-8", "fr_FR.UTF-8", "de_DE", "fr_FR"):
+            try:
+                locale.setlocale(locale.LC_NUMERIC, cand)
+                break
+            except locale.Error:
+                continue
+        else:
+            pytest.skip("no decimal-comma locale installed")
+        path = str(tmp_path / "loc.txt").encode()
+        b.parm_o2_min = 0.1 + 0.2
+        assert lib.obgc_params_write_text(path, C.byref(b), None, None) == 0
+        assert "," not in open(path.decode()).read()
+        lib2, b2, _, _ = _defaults(L)
+        assert lib.obgc_params_read_text(path, C.byref(b2), None, None, err, 256) == 0, err.value
+        assert b2.parm_o2_min == 0.1 + 0.2
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)
+
+
+def test_restart_file_in_the_native_layout_and_order_word(L, tmp_path):
+    lib = L.load()
+    nz, nc, ld = 5, 9, 12
+    rng = np.random.default_rng(5)
+    k_fast = [rng.standard_normal((nc, nz)), rng.standard_normal((nc, nz))]       # X(k,column): reference order
+    sp = [rng.standard_normal(nc), rng.standard_normal(nc)]
+    ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+    # the same state held column-fastest with a padded leading dimension
+    col_fast = [np.full((nz, ld), np.nan) for _ in range(2)]
+    for a, bb in zip(col_fast, k_fast):
+        a[:, :nc] = bb.T
+    g = L.Grid()
+    g.nlev, g.ncol, g.layout, g.memspace, g.ld = nz, nc, L.OBGC_LAYOUT_COLFAST, L.OBGC_MEM_HOST, ld
+    p1, p2 = str(tmp_path / "a.rst").encode(), str(tmp_path / "b.rst").encode()
+    assert lib.obgc_restart_write(p1, nz, nc, ptr(k_fast[0]), ptr(k_fast[1]), ptr(sp[0]), ptr(sp[1])) == 0
+    assert lib.obgc_restart_write_grid(p2, C.byref(g), ptr(col_fast[0]), ptr(col_fast[1]), ptr(sp[0]), ptr(sp[1])) == 0
+    assert open(p1.decode(), "rb").read() == open(p2.decode(), "rb").read()          # one file format
+    back = [np.full((nz, ld), -1.0) for _ in range(2)]
+    s2 = [np.zeros(nc), np.zeros(nc)]
+    assert lib.obgc_restart_read_grid(p1, C.byref(g), ptr(back[0]), ptr(back[1]), ptr(s2[0]), ptr(s2[1])) == 0
+    for a, bb in zip(back, k_fast):
+        assert np.array_equal(a[:, :nc], bb.T) and (a[:, nc:] == -1.0).all()
+    assert np.array_equal(s2[0], sp[0]) and np.array_equal(s2[1], sp[1])
+    g.memspace = L.OBGC_MEM_DEVICE                                                   # host arrays only
+    assert lib.obgc_restart_read_grid(p1, C.byref(g), ptr(back[0]), ptr(back[1]), ptr(s2[0]), ptr(s2[1])) == -1
+    # an order word other than 0 (level-fastest) is not defined: rejected
+    raw = bytearray(open(p1.decode(), "rb").read())
+    raw[16] = 1
+    open(p1.decode(), "wb").write(bytes(raw))
+    fl, fc = C.c_int(), C.c_int()
+    assert lib.obgc_restart_read_header(p1, C.byref(fl), C.byref(fc)) == -1
