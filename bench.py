@@ -164,7 +164,7 @@ def cpu_baseline(nz, modules, seconds_per_worker=3.0):
             orabind.build()
     ncpu = os.cpu_count() or 1
     cores = max(1, min(16, ncpu))          # a one-GPU box's CPU share is 16 cores whatever the machine has
-    per_cell_us = 5.0 * (1.0 + 0.15 * ("dms" in modules) + 0.05 * ("macros" in modules))     # ~5 us / cell / core
+    per_cell_us = 2.0 * (1.0 + 0.15 * ("dms" in modules) + 0.05 * ("macros" in modules))     # ~2 us / cell / core (EPYC host)
     per = max(64, int(seconds_per_worker / (per_cell_us * 1e-6 * nz)))
     jobs = [(kind, i * per, per, nz, tuple(modules)) for i in range(cores)]
     ctx = mp.get_context("spawn")
