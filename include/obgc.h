@@ -256,6 +256,17 @@ typedef struct {
 
 int obgc_dms_source_sink(obgc_handle *h, const obgc_dms_source_sink_args *a);
 
+/* obgc_dms_source_sink for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments, same kernels and the same
+ * bits as obgc_dms_source_sink, but the three-plane hand-off of the light pass lives in a fixed device array of the
+ * library instead of the handle's growing arena, so the call performs no hipMalloc / hipFree:
+ *   - DEVICE pointers in the native COLFAST layout only (anything else: OBGC_ERR_UNSUPPORTED);
+ *   - at most OBGC_NOALLOC_MAX_CELLS (k,column) elements per plane, padding included (else OBGC_ERR_UNSUPPORTED);
+ *   - the array is per GPU and shared by every handle on it: calls that overlap in time on one GPU race. */
+#define OBGC_NOALLOC_MAX_CELLS (1LL << 20)
+long long obgc_noalloc_max_cells(void);
+int obgc_dms_source_sink_noalloc(obgc_handle *h, const obgc_dms_source_sink_args *a);
+
 typedef struct {
 #define X(n) double *n;
   OBGC_DMS_FLUX_DIAG(X)

@@ -176,6 +176,8 @@ PROTOTYPES = {
     "obgc_bgc_source_sink": (C.c_int, [C.c_void_p, C.POINTER(BgcSourceSinkArgs)]),
     "obgc_bgc_surface_fluxes": (C.c_int, [C.c_void_p, C.POINTER(BgcSurfaceFluxesArgs)]),
     "obgc_dms_source_sink": (C.c_int, [C.c_void_p, C.POINTER(DmsSourceSinkArgs)]),
+    "obgc_noalloc_max_cells": (C.c_longlong, []),
+    "obgc_dms_source_sink_noalloc": (C.c_int, [C.c_void_p, C.POINTER(DmsSourceSinkArgs)]),
     "obgc_dms_surface_fluxes": (C.c_int, [C.c_void_p, C.POINTER(DmsSurfaceFluxesArgs)]),
     "obgc_macros_source_sink": (C.c_int, [C.c_void_p, C.POINTER(MacrosSourceSinkArgs)]),
     "obgc_apply_tendencies": (C.c_int, [C.c_void_p, C.POINTER(ApplyTendenciesArgs)]),

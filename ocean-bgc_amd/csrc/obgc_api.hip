@@ -292,6 +292,10 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
     delete h;
     return OBGC_ERR_HIP;
   }
+  if (noalloc_init_device(device_id) != hipSuccess) {   // address of the fixed scratch array on THIS GPU (obgc_noalloc.hip)
+    delete h;
+    return OBGC_ERR_HIP;
+  }
   hipEvent_t* evs[] = {&h->ev_begin, &h->ev_end, &h->ev_c0, &h->ev_c1, &h->ev_e0, &h->ev_e1, &h->ev_t0, &h->ev_t1, &h->ev_aux_done, &h->ev_aux2_done, &h->ev_k0, &h->ev_k1};
   for (auto e : evs)
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }

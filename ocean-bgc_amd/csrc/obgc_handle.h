@@ -48,4 +48,8 @@ inline int fail(obgc_handle* h, int code, const std::string& msg) {
       return fail(h, OBGC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
   } while (0)
 
+// One file-scope device array backs obgc_dms_source_sink_noalloc (obgc_noalloc.hip); obgc_create resolves its address
+// on the handle's GPU.  Returns hipSuccess or the error of the symbol lookup.
+hipError_t noalloc_init_device(int device);
+
 }  // namespace obgc

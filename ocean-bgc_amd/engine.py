@@ -190,7 +190,9 @@ class Engine:
         a.lcalc_CO2_gas_flux = 1 if lcalc_CO2_gas_flux else 0
         self._check(self.lib.obgc_bgc_surface_fluxes(self.h, C.byref(a)), "obgc_bgc_surface_fluxes")
 
-    def dms_source_sink(self, nlev, ncol, layout, tracers, dz, kmax, SST, sw_flux, tend, diag=None, ld=0, plane=0, ldc=0):
+    def dms_source_sink(self, nlev, ncol, layout, tracers, dz, kmax, SST, sw_flux, tend, diag=None, ld=0, plane=0, ldc=0,
+                        noalloc=False):
+        """noalloc=True: obgc_dms_source_sink_noalloc (fixed library scratch, no device allocation in the call)."""
         ms = self._memspace(tracers)
         a = L.DmsSourceSinkArgs()
         a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)
@@ -200,7 +202,8 @@ class Engine:
             d = L.DmsDiag()
             self._fill(d, L.DMS_DIAG_KC, diag, ms)
             a.diag = C.pointer(d)
-        self._check(self.lib.obgc_dms_source_sink(self.h, C.byref(a)), "obgc_dms_source_sink")
+        fn = "obgc_dms_source_sink_noalloc" if noalloc else "obgc_dms_source_sink"
+        self._check(getattr(self.lib, fn)(self.h, C.byref(a)), fn)
 
     def dms_surface_fluxes(self, nlev, ncol, layout, tracers, forcing, netFlux, diag=None, lcalc_DMS_gas_flux=True, ld=0,
                            plane=0, ldc=0):
