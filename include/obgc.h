@@ -303,6 +303,34 @@ typedef struct {
 
 int obgc_macros_source_sink(obgc_handle *h, const obgc_macros_source_sink_args *a);
 
+/* ------------------------------------------------------------- fused step
+ * BGC_SourceSink + DMS_SourceSink + MACROS_SourceSink over one batch in ONE call: what a host does that runs all three
+ * packages on the same columns every step (BGC_mod.F90:340, DMS_mod.F90:156, MACROS_mod.F90:137).  DMS reads twelve
+ * tracers it shares with BGC (no3, doc, zooC, spC, spCaCO3, diatC, diazC, phaeoC and the four Chl; DMS_mod.F90:471-482),
+ * MACROS five (zooC and the four C pools; MACROS_mod.F90:301-325): the host fills those slots of DMS_tracers /
+ * MACROS_tracers with copies of the BGC tracers.  Here they are READ ONCE from bgc.tracers, the light attenuation that
+ * BGC (BGC_mod.F90:907-924) and DMS (DMS_mod.F90:538-551) both compute from the same chlorophyll is computed once, and
+ * the cell terms of all three run on one set of loads.  Only each package's OWN tracers, their tendencies and the
+ * diagnostics are separate (k,column) planes, all in bgc.grid's index space.
+ *   - dz, kmax and ShortWaveFlux_surface of DMS / MACROS are bgc.dz, bgc.kmax, bgc.sw_flux.
+ *   - results are bit-identical to the three separate calls on DMS_tracers / MACROS_tracers filled that way; the twelve /
+ *     five tendency planes of the shared tracers, which the reference leaves zero, are not written.
+ *   - cells below kmax: the own tendencies are zero-filled, DMS / MACROS diagnostics are left alone (as the reference).
+ *   - dms == NULL skips DMS, prot == NULL skips MACROS; both NULL is obgc_bgc_source_sink.
+ *   - DEVICE pointers in the native COLFAST layout only (OBGC_ERR_UNSUPPORTED otherwise). */
+typedef struct {
+  obgc_bgc_source_sink_args bgc;
+  const double *dms, *dmsp;               /* DMS_tracers(k,column,dms_ind / dmsp_ind) */
+  const double *SST;                      /* DMS_forcing%SST(column) */
+  double *dms_tend, *dmsp_tend;           /* the two non-zero planes of DMS_tendencies */
+  const obgc_dms_diag *dms_diag;          /* NULL = none */
+  const double *prot, *poly, *lip;        /* MACROS_tracers(k,column,prot_ind / poly_ind / lip_ind) */
+  double *prot_tend, *poly_tend, *lip_tend;
+  const obgc_macros_diag *macros_diag;    /* NULL = none */
+} obgc_fused_step_args;
+
+int obgc_fused_step(obgc_handle *h, const obgc_fused_step_args *a);
+
 /* ------------------------------------------- resident tracers
  * NO reference counterpart: the reference returns tendencies and the host model owns the time
  * integration.  For a host that keeps its tracers on the GPU between steps this is the step right

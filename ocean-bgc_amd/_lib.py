@@ -97,6 +97,12 @@ class BgcSourceSinkArgs(C.Structure):
                 ("diag", C.POINTER(BgcDiag)), ("alt_co2_use_eco", C.c_int)]
 
 
+class FusedStepArgs(C.Structure):
+    _fields_ = [("bgc", BgcSourceSinkArgs), ("dms", _dptr), ("dmsp", _dptr), ("SST", _dptr), ("dms_tend", _dptr),
+                ("dmsp_tend", _dptr), ("dms_diag", C.POINTER(DmsDiag)), ("prot", _dptr), ("poly", _dptr), ("lip", _dptr),
+                ("prot_tend", _dptr), ("poly_tend", _dptr), ("lip_tend", _dptr), ("macros_diag", C.POINTER(MacrosDiag))]
+
+
 class BgcSurfaceFluxesArgs(C.Structure):
     _fields_ = [("grid", Grid), ("tracers", _dptr), ("surfacePressure", _dptr), ("windSpeedSquared10m", _dptr),
                 ("atmCO2", _dptr), ("atmCO2_ALT_CO2", _dptr), ("surfaceDepth", _dptr), ("SST", _dptr), ("SSS", _dptr),
@@ -174,6 +180,7 @@ PROTOTYPES = {
     "obgc_last_kernel_ms": (C.c_double, [C.c_void_p, C.c_int]),
     "obgc_last_schedule": (C.c_int, [C.c_void_p]),
     "obgc_bgc_source_sink": (C.c_int, [C.c_void_p, C.POINTER(BgcSourceSinkArgs)]),
+    "obgc_fused_step": (C.c_int, [C.c_void_p, C.POINTER(FusedStepArgs)]),
     "obgc_bgc_surface_fluxes": (C.c_int, [C.c_void_p, C.POINTER(BgcSurfaceFluxesArgs)]),
     "obgc_dms_source_sink": (C.c_int, [C.c_void_p, C.POINTER(DmsSourceSinkArgs)]),
     "obgc_noalloc_max_cells": (C.c_longlong, []),

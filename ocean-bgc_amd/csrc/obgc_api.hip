@@ -444,7 +444,7 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
 // OBGC_SCHED picks when the carbonate kernel is released: 1 (default) when the cell kernel ends, so that its
 // fp64 work overlaps the memory-bound sweep and the cell kernel has the register file to itself; 0 at t = 0;
 // 2 = solved inside the cell kernel's wavefronts (measured slower: two waves per SIMD cannot feed the VALU).
-int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
+int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F = nullptr) {
   // Large batches with diagnostics: the sweep (one wave per SIMD) is the longest kernel of the last phase and a
   // carbonate kernel beside it only slows it down (13.5 ms against 6.9 ms alone at 1 M columns), so the carbonate system
   // is solved inside the cell kernel's wavefronts instead: -4 % at 200 k - 1 M columns, +3 % at 100 k (measured).
@@ -453,7 +453,14 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat) {
   const int sched = h->sched >= 0 ? h->sched : (large ? (K.have_diag ? 2 : 0) : 1);
   h->last_sched = sched;
   HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
-  launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1, sched == 2);
+  if (F) {
+    FusedParams fp;
+    fp.dms = h->dms;
+    fp.macros = h->macros;
+    launch_fused_ecosys_cells(K, h->bgc, *F, fp, h->s_main, h->ev_k0, h->ev_k1, sched == 2);
+  } else {
+    launch_bgc_ecosys_cells(K, h->bgc, h->s_main, h->ev_k0, h->ev_k1, sched == 2);
+  }
   h->cell_valid = true;
   HIP_TRY(h, hipStreamWaitEvent(h->s_aux, sched == 0 ? h->ev_e0 : h->ev_k1, 0));
   HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
@@ -907,6 +914,78 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   rc = stage_out(h, st, chunked);
   if (rc != OBGC_OK) return rc;
   return finish(h, st.host);
+}
+
+// ============================================================================ fused step ==
+// BGC_SourceSink + DMS_SourceSink + MACROS_SourceSink of one batch in one call (BASELINE config "BGC + DMS + MACROS fused
+// tendencies").  The kernels are those of obgc_bgc_source_sink with the other two modules' cell terms folded into the
+// attenuation, scan and cell kernels: one light pass, the shared tracers read once.
+
+extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
+  if (!h || !a) return OBGC_ERR_INVALID;
+  const obgc_bgc_source_sink_args& b = a->bgc;
+  if (!grid_ok(b.grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
+  if (!a->dms && !a->prot) return obgc_bgc_source_sink(h, &a->bgc);   // nothing to fuse
+  if (b.grid.memspace != OBGC_MEM_DEVICE || b.grid.layout != OBGC_LAYOUT_COLFAST)
+    return fail(h, OBGC_ERR_UNSUPPORTED,
+                "obgc_fused_step: device pointers in the native column-fastest layout only; for host memory or the reference "
+                "layout call obgc_bgc_source_sink, obgc_dms_source_sink and obgc_macros_source_sink");
+  if (b.grid.ncol == 0) return OBGC_OK;
+  if (!b.tracers || !b.temp || !b.salt || !b.zmid || !b.dz || !b.zbot || !b.lat || !b.kmax || !b.fesedflux || !b.dust_flux_in ||
+      !b.sw_flux || !b.tend || !b.ph_prev || !b.ph_prev_alt)
+    return fail(h, OBGC_ERR_INVALID, "obgc_fused_step: null BGC array");
+  if (a->dms && (!a->dmsp || !a->SST || !a->dms_tend || !a->dmsp_tend)) return fail(h, OBGC_ERR_INVALID, "obgc_fused_step: null DMS array");
+  if (a->prot && (!a->poly || !a->lip || !a->prot_tend || !a->poly_tend || !a->lip_tend))
+    return fail(h, OBGC_ERR_INVALID, "obgc_fused_step: null MACROS array");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const GridView v = make_view(b.grid);
+  h->arena_used = 0;
+  h->timed_valid = false;
+  h->tr_valid = false;
+  h->cell_valid = false;
+  const bool want_zsat = b.diag && (b.diag->zsatcalc || b.diag->zsatarag);
+  const size_t kc1 = span_kc(v, 1);
+  const size_t dms_scratch = a->dms ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
+  int rc = arena_reserve(h, bgc_scratch_bytes(v, b.diag, want_zsat, false) + dms_scratch);
+  if (rc != OBGC_OK) return rc;
+
+  BgcKernelArgs K;
+  std::memset(&K, 0, sizeof K);
+  K.g = v;
+  K.tracers = b.tracers;
+  K.temp = b.temp; K.salt = b.salt; K.zmid = b.zmid; K.dz = b.dz; K.zbot = b.zbot; K.fesed = b.fesedflux;
+  K.lat = b.lat; K.kmax = b.kmax; K.dust = b.dust_flux_in; K.sw = b.sw_flux;
+  K.tend = b.tend; K.ph_prev = b.ph_prev; K.ph_prev_alt = b.ph_prev_alt;
+  if (b.diag) K.diag = *b.diag;
+  K.have_diag = b.diag ? 1 : 0;
+  K.alt_co2_use_eco = b.alt_co2_use_eco;
+  bgc_carve_scratch(h, K, want_zsat);
+
+  FusedDmArgs F;
+  std::memset(&F, 0, sizeof F);
+  F.dms = a->dms; F.dmsp = a->dmsp; F.SST = a->SST; F.dms_tend = a->dms_tend; F.dmsp_tend = a->dmsp_tend;
+  F.prot = a->prot; F.poly = a->poly; F.lip = a->lip; F.prot_tend = a->prot_tend; F.poly_tend = a->poly_tend; F.lip_tend = a->lip_tend;
+  if (a->dms && a->dms_diag) { F.ddiag = *a->dms_diag; F.have_ddiag = 1; }
+  if (a->prot && a->macros_diag) { F.mdiag = *a->macros_diag; F.have_mdiag = 1; }
+  F.f_qsw_par_dms = h->dms.f_qsw_par_DMS;
+  F.all_flagged = (h->dms.f_qsw_par_DMS != 0.45) ? 1 : 0;   // BGC's f_qsw_par is the constant 0.45 (BGC_parms.F90:454-455)
+  if (a->dms) {
+    auto carve = [&](size_t bytes) -> void* {
+      void* p = h->arena + h->arena_used;
+      h->arena_used += align_up(bytes);
+      return p;
+    };
+    F.d_att = (double*)carve(kc1); F.d_kpardz = (double*)carve(kc1); F.d_parin = (double*)carve(kc1);
+    F.flag = (int*)carve((size_t)v.ncol * sizeof(int));
+    HIP_TRY(h, hipMemsetAsync(F.flag, 0, (size_t)v.ncol * sizeof(int), h->s_main));
+  }
+  HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
+  rc = bgc_launch(h, K, want_zsat, &F);
+  if (rc != OBGC_OK) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev_end, h->s_main));
+  HIP_TRY(h, hipGetLastError());
+  h->timed_valid = true;
+  return finish(h, false);
 }
 
 // *_SurfaceFluxes read the surface row of a few tracers (BGC_mod.F90:2816-2822, DMS_mod.F90:834).  A host-memory caller

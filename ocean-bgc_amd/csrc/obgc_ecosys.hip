@@ -28,6 +28,7 @@
 // are added) and P_iron production (Fe scavenging added last); the change is a few ulp of the
 // largest term, far inside the parity bar, and is listed in DESIGN.md.
 #include "obgc_co2.h"
+#include "obgc_dm.h"
 
 namespace obgc {
 
@@ -91,7 +92,8 @@ __device__ __forceinline__ double uniform(double v) {
 // Masked, clamped autotroph pools of one cell (BGC_mod.F90:764-785, 826-844)
 struct Pools { double Chl[4], C[4], Fe[4], Si[4], Ca[4]; };
 
-__device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_autotroph* at, long long ix, Pools& p) {
+// chl0: the clamped chlorophyll before the zero-mask (what DMS_SourceSink sums, DMS_mod.F90:478-481, 539)
+__device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_autotroph* at, long long ix, Pools& p, double (&chl0)[4]) {
   const long long pl = A.g.plane;
   // all loads first and unconditional (an autotroph without Si reads its C plane again and discards it): one
   // wait for the whole batch instead of one memory round trip per uniform branch
@@ -106,6 +108,7 @@ __device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_au
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     p.Chl[a] = dmax(0.0, p.Chl[a]);
+    chl0[a] = p.Chl[a];
     p.C[a] = dmax(0.0, p.C[a]);
     p.Fe[a] = dmax(0.0, p.Fe[a]);
     p.Si[a] = (at[a].Si_ind > 0) ? dmax(0.0, si[a]) : 0.0;
@@ -117,17 +120,25 @@ __device__ __forceinline__ void load_pools(const BgcKernelArgs& A, const obgc_au
 }
 
 // Morel & Maritorena attenuation across one level (BGC_mod.F90:914-921)
-__device__ __forceinline__ double kpar_dz(const double (&Chl)[4], double dz) {
-  const double w1 = dmax(sum4(Chl), 0.02);
-  const double K = (w1 < 0.13224) ? 0.000919 * pow(w1, 0.3536) : 0.001131 * pow(w1, 0.4562);
-  return K * dz;
+__device__ __forceinline__ double kpar_dz(const double (&Chl)[4], double dz) { return kpar_dz_of(sum4(Chl), dz); }
+
+// uniform (scalar) index into a 4-element register array without making it addressable
+__device__ __forceinline__ double sel4(const double (&v)[4], int a) {
+  return a == 0 ? v[0] : (a == 1 ? v[1] : (a == 2 ? v[2] : v[3]));
+}
+
+// total chlorophyll as DMS_SourceSink adds it up: sp + diat + diaz + phaeo (DMS_mod.F90:539-540)
+__device__ __forceinline__ double dms_total_chl(const double (&chl)[4], const obgc_bgc_params& P) {
+  return ((sel4(chl, P.sp_ind - 1) + sel4(chl, P.diat_ind - 1)) + sel4(chl, P.diaz_ind - 1)) + sel4(chl, P.phaeo_ind - 1);
 }
 
 // ------------------------------------------------------------------------- light: attenuation + scan
 // Attenuation of PAR across each level is cell-local (one pow + one exp, BGC_mod.F90:914-923); only the
 // product down the column is sequential.  One lane per cell computes exp(-KPARdz); the scan kernel then
 // needs a single multiply per level.
-__global__ __launch_bounds__(256) void bgc_att_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+// dms_flag (fused step only, else NULL): set for a column as soon as one of its cells has a DMS chlorophyll total that is
+// not, bit for bit, the total BGC attenuates with; such a column gets a DMS light pass of its own from the scan kernel.
+__device__ __forceinline__ void att_body(const BgcKernelArgs& A, const obgc_bgc_params& P, int* dms_flag) {
   const GridView& g = A.g;
   const long long ncell = (long long)g.nlev * g.ncol;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -138,19 +149,26 @@ __global__ __launch_bounds__(256) void bgc_att_kernel(const BgcKernelArgs A, con
   if (k >= A.kmax[c]) return;
   const long long ix = g.at(k, c);
   Pools p;
-  load_pools(A, P.autotrophs, ix, p);
+  double chl0[4];
+  load_pools(A, P.autotrophs, ix, p, chl0);
   const double KPARdz = kpar_dz(p.Chl, A.dz[ix]);
   A.scratch[(long long)S_KPARDZ * A.splane + ix] = KPARdz;
   A.scratch[(long long)S_ATT * A.splane + ix] = exp(-KPARdz);
+  if (dms_flag && dms_total_chl(chl0, P) != sum4(p.Chl)) dms_flag[c] = 1;   // every writer stores the same value
 }
 
-__global__ __launch_bounds__(kBlockCol) void bgc_parscan_kernel(const BgcKernelArgs A) {
+__global__ __launch_bounds__(256) void bgc_att_kernel(const BgcKernelArgs A, const obgc_bgc_params P) { att_body(A, P, nullptr); }
+__global__ __launch_bounds__(256) void fused_att_kernel(const BgcKernelArgs A, const obgc_bgc_params P, int* dms_flag) {
+  att_body(A, P, dms_flag);
+}
+
+// the scan for one column; returns false for a column without active levels
+__device__ __forceinline__ bool parscan_body(const BgcKernelArgs& A, int c, int& kmax_out) {
   const GridView& g = A.g;
-  const int c = blockIdx.x * kBlockCol + threadIdx.x;
-  if (c >= g.ncol) return;
   int kmax = A.kmax[c];
   if (kmax > g.nlev) kmax = g.nlev;
-  if (kmax < 1) return;
+  kmax_out = kmax;
+  if (kmax < 1) return false;
   const double* att = A.scratch + (long long)S_ATT * A.splane;
   double* par_in = A.scratch + (long long)S_PARIN * A.splane;
   double PAR = dmax(0.0, A.sw[c]) * F_QSW_PAR;                     // BGC_mod.F90:813-814
@@ -163,6 +181,40 @@ __global__ __launch_bounds__(kBlockCol) void bgc_parscan_kernel(const BgcKernelA
     for (int j = 0; j < 8; ++j) { par_in[g.at(k + j, c)] = PAR; PAR = PAR * a[j]; }   // PAR_out = PAR_in * exp(-KPARdz), 923
   }
   for (; k < kmax; ++k) { par_in[g.at(k, c)] = PAR; PAR = PAR * att[g.at(k, c)]; }
+  return true;
+}
+
+__global__ __launch_bounds__(kBlockCol) void bgc_parscan_kernel(const BgcKernelArgs A) {
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if (c >= A.g.ncol) return;
+  int kmax;
+  (void)parscan_body(A, c, kmax);
+}
+
+// Fused step: the same scan, and for flagged columns the whole light pass of DMS_SourceSink (DMS_mod.F90:506-507, 538-551)
+// from the clamped chlorophyll of the BGC tracer array.  Rare (a pool the zero-mask removes while it still holds
+// chlorophyll), so one lane per column with a pow and an exp per level is good enough.
+__global__ __launch_bounds__(kBlockCol) void fused_parscan_kernel(const BgcKernelArgs A, const obgc_bgc_params P, const FusedDmArgs F) {
+  const GridView& g = A.g;
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if (c >= g.ncol) return;
+  int kmax;
+  if (!parscan_body(A, c, kmax)) return;
+  if (!F.dms || !(F.all_flagged || F.flag[c])) return;
+  const long long pl = g.plane;
+  double PAR = dmax(0.0, A.sw[c]) * F.f_qsw_par_dms;
+  for (int k = 0; k < kmax; ++k) {
+    const long long ix = g.at(k, c);
+    double chl[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) chl[a] = dmax(0.0, A.tracers[(long long)(P.autotrophs[a].Chl_ind - 1) * pl + ix]);
+    const double KPARdz = kpar_dz_of(dms_total_chl(chl, P), A.dz[ix]);
+    const double att = exp(-KPARdz);
+    F.d_kpardz[ix] = KPARdz;
+    F.d_att[ix] = att;
+    F.d_parin[ix] = PAR;
+    PAR = PAR * att;
+  }
 }
 
 // ------------------------------------------------------------------------------- cell kernel
@@ -198,13 +250,15 @@ __device__ __forceinline__ Pool1 mask_pool(const obgc_autotroph& t, Pool1 p) {
   return p;
 }
 
-// uniform (scalar) index into a 4-element register array without making it addressable
-__device__ __forceinline__ double sel4(const double (&v)[4], int a) {
-  return a == 0 ? v[0] : (a == 1 ? v[1] : (a == 2 ? v[2] : v[3]));
+__device__ __forceinline__ double pick_C(const Pool1 (&r)[4], int a) { return a == 0 ? r[0].C : (a == 1 ? r[1].C : (a == 2 ? r[2].C : r[3].C)); }
+__device__ __forceinline__ double pick_Chl(const Pool1 (&r)[4], int a) {
+  return a == 0 ? r[0].Chl : (a == 1 ? r[1].Chl : (a == 2 ? r[2].Chl : r[3].Chl));
 }
 
-template <bool DIAG>
-__device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc_params& P) {
+// DM: DMS_SourceSink and MACROS_SourceSink of the same cell are evaluated too (obgc_fused_step): the tracers they share
+// with BGC are in registers already, only their own five tracers are extra loads.
+template <bool DIAG, bool DM>
+__device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, const FusedParams* FP) {
   const GridView& g = A.g;
   const long long ncell = (long long)g.nlev * g.ncol;
   const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
@@ -225,6 +279,8 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   // requests per lane and a single memory round trip per wavefront.  Cells below the sea floor load too (valid
   // addresses, values discarded) so that the kmax test does not cost a round trip of its own.
   int kmax = A.kmax[c];
+  bool dflag = false;   // this column has a DMS light pass of its own
+  if (DM && F->dms) dflag = F->all_flagged || F->flag[c] != 0;
   const double lat = A.lat[c];
   const double T = A.temp[ix], dz = A.dz[ix], zc = A.zmid[ix];
   const double r_PO4 = RAW(P.ind[0]), r_NO3 = RAW(P.ind[1]), r_SiO3 = RAW(P.ind[2]), r_NH4 = RAW(P.ind[3]), r_Fe = RAW(P.ind[4]),
@@ -240,10 +296,22 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   Pool1 raw[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) raw[a] = load_pool_raw(A, at[a], ix);
+  double o_dms = 0.0, o_dmsp = 0.0, o_sst = 0.0, o_spca = 0.0, o_prot = 0.0, o_poly = 0.0, o_lip = 0.0;
+  double d_parin = 0.0, d_att = 0.0, d_kpardz = 1.0;
+  if (DM) {
+    if (F->dms) { o_dms = F->dms[ix]; o_dmsp = F->dmsp[ix]; o_sst = F->SST[c]; o_spca = RAW(P.ind[19]); }
+    if (F->prot) { o_prot = F->prot[ix]; o_poly = F->poly[ix]; o_lip = F->lip[ix]; }
+    if (dflag) { d_parin = F->d_parin[ix]; d_att = F->d_att[ix]; d_kpardz = F->d_kpardz[ix]; }   // last: the only dependent loads
+  }
   if (kmax > g.nlev) kmax = g.nlev;
 
   if (k >= kmax) {
-    // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727)
+    // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727; DMS_mod.F90:413,
+    // MACROS_mod.F90:267 for the tendencies of the other two modules, whose diagnostics it leaves alone)
+    if (DM) {
+      if (F->dms) { F->dms_tend[ix] = 0.0; F->dmsp_tend[ix] = 0.0; }
+      if (F->prot) { F->prot_tend[ix] = 0.0; F->poly_tend[ix] = 0.0; F->lip_tend[ix] = 0.0; }
+    }
 #pragma unroll 6
     for (int n = 0; n < OBGC_BGC_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
     if (DIAG) {
@@ -275,6 +343,31 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   // light (907-924): attenuation and PAR entering the level come from the att / scan kernels
   const double PAR_out = PAR_in * att;
   const double PAR_avg = PAR_in * (1.0 - att) / KPARdz;
+
+  if (DM) {
+    // DMS_SourceSink (DMS_mod.F90:516-761) and MACROS_SourceSink (MACROS_mod.F90:331-406) of this cell, first: every value
+    // they need is loaded, nothing of theirs stays live afterwards.  They see the clamped tracers, not the zero-masked pools.
+    const double c_zoo = dmax(0.0, r_zooC), c_sp = dmax(0.0, pick_C(raw, P.sp_ind - 1)), c_diat = dmax(0.0, pick_C(raw, P.diat_ind - 1)),
+                 c_diaz = dmax(0.0, pick_C(raw, P.diaz_ind - 1)), c_phaeo = dmax(0.0, pick_C(raw, P.phaeo_ind - 1));
+    if (F->dms) {
+      // the level mean of PAR as DMS computes it (551): BGC's own value unless the column has its own light pass
+      const double PAR_avg_dms = dflag ? d_parin * (1.0 - d_att) / d_kpardz : PAR_avg;
+      const DmsColumn col = dms_column_terms(FP->dms, o_sst);
+      double t_dms, t_dmsp;
+      dms_cell_terms<true>(FP->dms, F->ddiag, ix, col, dmax(0.0, o_dms), dmax(0.0, o_dmsp), c_zoo, c_sp, dmax(0.0, o_spca), c_diat,
+                           c_diaz, c_phaeo, dmax(0.0, pick_Chl(raw, P.sp_ind - 1)), PAR_avg_dms, t_dms, t_dmsp);
+      F->dms_tend[ix] = t_dms;
+      F->dmsp_tend[ix] = t_dmsp;
+    }
+    if (F->prot) {
+      double t_prot, t_poly, t_lip;
+      macros_cell_terms<true>(FP->macros, F->mdiag, ix, c_zoo, c_sp, c_diat, c_diaz, c_phaeo, dmax(0.0, o_prot), dmax(0.0, o_poly),
+                              dmax(0.0, o_lip), t_prot, t_poly, t_lip);
+      F->prot_tend[ix] = t_prot;
+      F->poly_tend[ix] = t_poly;
+      F->lip_tend[ix] = t_lip;
+    }
+  }
 
   // Everything below the autotroph loop that needs a global LOAD is evaluated now and parked in LDS: loads and
   // stores retire through one in-order counter, so a load issued after the loop's ~100 diagnostic stores would
@@ -618,18 +711,31 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
 // memory pipeline against ~6 600 fp64 VALU instructions -- and as separate kernels their waves compete for
 // the register file instead of overlapping (the cell kernel fills a SIMD with two waves).  In one wave the
 // stores drain under the Newton iterations and the co-resident wave's loads hide under them.
+__device__ __forceinline__ void carbonate_of_this_lane(const BgcKernelArgs& A, const obgc_bgc_params& P) {
+  const GridView& g = A.g;
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  carbonate_cell(A, P.ind[6], P.ind[8], P.ind[0], P.ind[2], idx < ncell, k, c);
+}
+
 template <bool DIAG, int FUSE>
 __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
-  cell_body<DIAG>(A, P);
-  if (FUSE) {
-    const GridView& g = A.g;
-    const long long ncell = (long long)g.nlev * g.ncol;
-    const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
-    int k, c;
-    if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
-    else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
-    carbonate_cell(A, P.ind[6], P.ind[8], P.ind[0], P.ind[2], idx < ncell, k, c);
-  }
+  cell_body<DIAG, false>(A, P, nullptr, nullptr);
+  if (FUSE) carbonate_of_this_lane(A, P);
+}
+
+static_assert(sizeof(BgcKernelArgs) + sizeof(obgc_bgc_params) + sizeof(FusedDmArgs) + sizeof(FusedParams) <= 4096,
+              "kernel arguments of the fused cell kernel must fit the 4 KB kernarg segment");
+
+// the cell kernel of obgc_fused_step: BGC + DMS + MACROS terms of a cell from one set of loads
+template <bool DIAG, int FUSE>
+__global__ __launch_bounds__(kBlockCell, 2) void fused_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P, const FusedDmArgs F,
+                                                                   const FusedParams FP) {
+  cell_body<DIAG, true>(A, P, &F, &FP);
+  if (FUSE) carbonate_of_this_lane(A, P);
 }
 
 // ------------------------------------------------------------------------------ particle sweep
@@ -978,6 +1084,24 @@ void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, h
   launch_bgc_parscan(a, s);
   if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
   launch_bgc_cell(a, p, s, fuse_carbonate);
+  if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
+}
+
+void launch_fused_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, const FusedDmArgs& f, const FusedParams& fp, hipStream_t s,
+                               hipEvent_t ev_cell0, hipEvent_t ev_cell1, int fuse_carbonate) {
+  const long long ncell = (long long)a.g.nlev * a.g.ncol;
+  if (ncell <= 0) return;
+  hipLaunchKernelGGL(fused_att_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, p, f.dms ? f.flag : nullptr);
+  hipLaunchKernelGGL(fused_parscan_kernel, dim3((unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol)), dim3(kBlockCol), 0, s, a, p, f);
+  if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
+  const unsigned gcell = (unsigned)((ncell + kBlockCell - 1) / kBlockCell);
+  if (fuse_carbonate) {
+    if (a.have_diag) hipLaunchKernelGGL((fused_cell_kernel<true, 1>), dim3(gcell), dim3(kBlockCell), 0, s, a, p, f, fp);
+    else hipLaunchKernelGGL((fused_cell_kernel<false, 1>), dim3(gcell), dim3(kBlockCell), 0, s, a, p, f, fp);
+  } else {
+    if (a.have_diag) hipLaunchKernelGGL((fused_cell_kernel<true, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p, f, fp);
+    else hipLaunchKernelGGL((fused_cell_kernel<false, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p, f, fp);
+  }
   if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
 }
 

@@ -66,6 +66,27 @@ struct BgcKernelArgs {
   int alt_co2_use_eco;
 };
 
+// DMS_SourceSink + MACROS_SourceSink folded into the BGC kernels (obgc_fused_step).  The tracers both modules share with
+// BGC are read from the BGC tracer array; only their own tracers, tendencies and diagnostics are separate planes in the
+// same (k,column) index space.
+struct FusedDmArgs {
+  const double *dms, *dmsp, *SST;       // dms == NULL: no DMS part
+  double *dms_tend, *dmsp_tend;
+  const double *prot, *poly, *lip;      // prot == NULL: no MACROS part
+  double *prot_tend, *poly_tend, *lip_tend;
+  obgc_dms_diag ddiag;
+  obgc_macros_diag mdiag;
+  int have_ddiag, have_mdiag;
+  // DMS attenuates PAR with the clamped chlorophyll (DMS_mod.F90:539-548), BGC with the clamped AND zero-masked one
+  // (BGC_mod.F90:826-844, 914-921).  Where the two sums are the same bits -- everywhere unless the mask removes a pool with
+  // chlorophyll left in it -- DMS shares BGC's light pass; a column with a cell where they differ is flagged by the
+  // attenuation kernel and gets a DMS light pass of its own from the scan kernel (three planes, flagged columns only).
+  int* flag;                            // (column), zeroed before the attenuation kernel
+  int all_flagged;                      // f_qsw_par_DMS differs from BGC's 0.45: nothing can be shared
+  double f_qsw_par_dms;
+  double *d_att, *d_kpardz, *d_parin;
+};
+
 struct SurfKernelArgs {
   GridView g;
   const double* tracers;
@@ -151,6 +172,13 @@ void launch_transpose_table_c2k(const PlaneTable& t, int nlev, int ncol, long lo
 void launch_bgc_att(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_parscan(const BgcKernelArgs& a, hipStream_t s);
 void launch_bgc_cell(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int fuse_carbonate);
+// the same three with DMS / MACROS folded in (obgc_fused_step)
+struct FusedParams {
+  obgc_dms_params dms;
+  obgc_macros_params macros;
+};
+void launch_fused_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, const FusedDmArgs& f, const FusedParams& fp, hipStream_t s,
+                               hipEvent_t ev_cell0, hipEvent_t ev_cell1, int fuse_carbonate);
 
 // device ordinal a handle was created on (obgc_api.hip owns the handle's definition)
 int handle_device(const obgc_handle* h);

@@ -171,6 +171,43 @@ class Engine:
         a.alt_co2_use_eco = 1 if alt_co2_use_eco else 0
         return (C.byref(a), a, d)          # byref object + what it points to (kept alive by the tuple)
 
+    # ---- fused BGC + DMS + MACROS step (obgc_fused_step) ----
+    FUSED_EXTRA = ("dms", "dmsp", "SST", "dms_tend", "dmsp_tend", "prot", "poly", "lip", "prot_tend", "poly_tend", "lip_tend")
+
+    def fused_step_prepare(self, nlev, ncol, layout, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesedflux, dust_flux_in,
+                           sw_flux, tend, ph_prev, ph_prev_alt, diag=None, alt_co2_use_eco=True, ld=0, plane=0, ldc=0,
+                           dms_diag=None, macros_diag=None, **own):
+        """own: dms, dmsp, SST, dms_tend, dmsp_tend (DMS part) and / or prot, poly, lip, prot_tend, poly_tend, lip_tend
+        (MACROS part): (k,column) planes in the same index space as the BGC arrays; SST is (column)."""
+        _, a_bgc, d_bgc = self.bgc_source_sink_prepare(nlev, ncol, layout, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesedflux,
+                                                       dust_flux_in, sw_flux, tend, ph_prev, ph_prev_alt, diag, alt_co2_use_eco,
+                                                       ld, plane, ldc)
+        ms = a_bgc.grid.memspace
+        a = L.FusedStepArgs()
+        a.bgc = a_bgc
+        bad = set(own) - set(self.FUSED_EXTRA)
+        if bad:
+            raise ObgcError("fused_step: unknown arrays %s" % sorted(bad))
+        self._fill(a, [n for n in self.FUSED_EXTRA if own.get(n) is not None], own, ms)
+        keep = [d_bgc]
+        if dms_diag is not None:
+            d = L.DmsDiag()
+            self._fill(d, L.DMS_DIAG_KC, dms_diag, ms)
+            a.dms_diag = C.pointer(d)
+            keep.append(d)
+        if macros_diag is not None:
+            d = L.MacrosDiag()
+            self._fill(d, L.MACROS_DIAG_KC, macros_diag, ms)
+            a.macros_diag = C.pointer(d)
+            keep.append(d)
+        return (C.byref(a), a, keep)
+
+    def fused_step_run(self, prepared):
+        self._check(self.lib.obgc_fused_step(self.h, prepared[0]), "obgc_fused_step")
+
+    def fused_step(self, *args, **kw):
+        self.fused_step_run(self.fused_step_prepare(*args, **kw))
+
     def bgc_surface_fluxes(self, nlev, ncol, layout, tracers, forcing, depositionFlux, riverFlux, gasFlux, seaIceFlux,
                            netFlux, diag=None, lcalc_O2_gas_flux=True, lcalc_CO2_gas_flux=True, ld=0, plane=0, ldc=0):
         ms = self._memspace(tracers)

@@ -132,6 +132,72 @@ class ColumnEngine:
             out["c"] = {nm: self._down(diag[nm], "c") for nm in L.BGC_DIAG_C}
         return out
 
+    # ---- BGC_SourceSink + DMS_SourceSink + MACROS_SourceSink in one call (obgc_fused_step) ----
+    def Fused_SourceSink(self, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesed, dust, sw, ph_prev, ph_prev_alt, sst,
+                         dms_tracers=None, macros_tracers=None, alt_co2_use_eco=True, diag_init=0.0, diagnostics=True):
+        """dms_tracers / macros_tracers: the reference's 14- / 8-plane arrays [n, ncol, nlev]; only the OWN planes (dms, dmsp /
+        prot, poly, lip at the slots of the engine's DMS / MACROS indices) are handed to the library, the shared ones must be
+        copies of the BGC tracers (asserted).  Returns {"bgc", "dms", "macros"} shaped like the three separate routines'
+        results; the tendency planes of the shared tracers, which the fused step does not write, are returned as zeros."""
+        if self.path != "device_colfast":
+            raise ValueError("the fused step runs on device-resident arrays in the native layout")
+        n, nc, nz = tracers.shape
+        up = self._up
+        E = self.eng
+        tend = up(np.full((30, nc, nz), diag_init), "kc")
+        php, pha = up(ph_prev, "kc"), up(ph_prev_alt, "kc")
+        diag = None
+        if diagnostics:
+            diag = {}
+            for nm in L.BGC_DIAG_KC:
+                diag[nm] = up(np.full((nc, nz), diag_init), "kc")
+            for nm in L.BGC_DIAG_KCA:
+                diag[nm] = up(np.full((4, nc, nz), diag_init), "kc")
+            for nm in L.BGC_DIAG_CA:
+                diag[nm] = up(np.full((4, nc), diag_init), "c")
+            for nm in L.BGC_DIAG_C:
+                diag[nm] = up(np.full((nc,), diag_init), "c")
+        own, ddiag, mdiag = {}, None, None
+        bslot = {nm: E.bgc.ind[i] - 1 for i, nm in enumerate(L.BGC_TRACERS)}
+        if dms_tracers is not None:
+            ds = [E.dms.ind[i] - 1 for i in range(14)]
+            for j, nm in enumerate(L.DMS_TRACERS[2:], start=2):
+                assert np.array_equal(dms_tracers[ds[j]], tracers[bslot[nm]]), "DMS tracer %s is not the BGC tracer" % nm
+            own.update(dms=up(dms_tracers[ds[0]], "kc"), dmsp=up(dms_tracers[ds[1]], "kc"), SST=up(sst, "c"),
+                       dms_tend=up(np.full((nc, nz), diag_init), "kc"), dmsp_tend=up(np.full((nc, nz), diag_init), "kc"))
+            if diagnostics:
+                ddiag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.DMS_DIAG_KC}
+        if macros_tracers is not None:
+            ms = [E.macros.ind[i] - 1 for i in range(8)]
+            for j, nm in enumerate(L.MACROS_TRACERS[3:], start=3):
+                assert np.array_equal(macros_tracers[ms[j]], tracers[bslot[nm]]), "MACROS tracer %s is not the BGC tracer" % nm
+            own.update(prot=up(macros_tracers[ms[0]], "kc"), poly=up(macros_tracers[ms[1]], "kc"), lip=up(macros_tracers[ms[2]], "kc"),
+                       prot_tend=up(np.full((nc, nz), diag_init), "kc"), poly_tend=up(np.full((nc, nz), diag_init), "kc"),
+                       lip_tend=up(np.full((nc, nz), diag_init), "kc"))
+            if diagnostics:
+                mdiag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.MACROS_DIAG_KC}
+        E.fused_step(nz, nc, self._layout, up(tracers, "kc"), up(temp, "kc"), up(salt, "kc"), up(zmid, "kc"), up(dz, "kc"),
+                     up(zbot, "kc"), up(lat, "c"), up(np.asarray(kmax, dtype=np.int32), "c"), up(fesed, "kc"), up(dust, "c"),
+                     up(sw, "c"), tend, php, pha, diag, alt_co2_use_eco, dms_diag=ddiag, macros_diag=mdiag, **own)
+        dn = self._down
+        bgc = dict(tend=dn(tend, "kc"), ph_prev=dn(php, "kc"), ph_prev_alt=dn(pha, "kc"), kc={}, kca={}, ca={}, c={})
+        if diagnostics:
+            bgc["kc"] = {nm: dn(diag[nm], "kc") for nm in L.BGC_DIAG_KC}
+            bgc["kca"] = {nm: dn(diag[nm], "kc") for nm in L.BGC_DIAG_KCA}
+            bgc["ca"] = {nm: dn(diag[nm], "c") for nm in L.BGC_DIAG_CA}
+            bgc["c"] = {nm: dn(diag[nm], "c") for nm in L.BGC_DIAG_C}
+        out = dict(bgc=bgc)
+        if dms_tracers is not None:
+            t = np.zeros((14, nc, nz))
+            t[ds[0]], t[ds[1]] = dn(own["dms_tend"], "kc"), dn(own["dmsp_tend"], "kc")
+            out["dms"] = dict(tend=t, kc={nm: dn(v, "kc") for nm, v in ddiag.items()} if ddiag else {})
+        if macros_tracers is not None:
+            t = np.zeros((8, nc, nz))
+            for j, nm in enumerate(("prot_tend", "poly_tend", "lip_tend")):
+                t[ms[j]] = dn(own[nm], "kc")
+            out["macros"] = dict(tend=t, kc={nm: dn(v, "kc") for nm, v in mdiag.items()} if mdiag else {})
+        return out
+
     # ---- BGC_SurfaceFluxes (BGC_mod.F90:2706) ----
     def BGC_SurfaceFluxes(self, tracers, forcing, depo, river, gas, seaice, net=None, lcalc_o2=True, lcalc_co2=True,
                           diag_init=0.0):
