@@ -300,6 +300,7 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   for (auto e : evs)
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_COLUMN_KERNEL")) h->column = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_HYBRID")) h->kfast_hybrid = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
   if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
@@ -389,7 +390,9 @@ namespace {
 
 
 // bytes of engine scratch obgc_bgc_source_sink needs for the view the kernels run on
-size_t bgc_scratch_bytes(const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat, bool workspace_has_all) {
+// `column`: the column-block kernel keeps the light and the hand-off on the chip; only the chlorophyll profile of the 100 m
+// integral goes through memory
+size_t bgc_scratch_bytes(const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat, bool workspace_has_all, bool column = false) {
   const size_t kc1 = span_kc(kv, 1);
   size_t bytes = 0;
   if (want_zsat) {
@@ -399,8 +402,9 @@ size_t bgc_scratch_bytes(const GridView& kv, const obgc_bgc_diag* diag, bool wan
   }
   const long long span1 = (long long)(kc1 / sizeof(double));
   const long long splane = (span1 + 31) & ~31LL;
-  const int nslots = diag ? (int)S_NDIAG : (int)S_NBASE;
+  const int nslots = column ? (diag ? 5 : 0) : (diag ? (int)S_NDIAG : (int)S_NBASE);
   bytes += align_up((size_t)nslots * splane * sizeof(double));
+  if (column && diag) bytes += align_up((size_t)3 * kv.ncol * sizeof(double));
   if (diag) {
     const size_t zbytes = align_up((size_t)(3 * kv.plane + span1) * sizeof(double));
     const int nfb = (diag->photoC ? 0 : 1) + (diag->photoC_NO3 ? 0 : 1) + (diag->CaCO3_form ? 0 : 1) + (diag->bSi_form ? 0 : 1);
@@ -411,7 +415,7 @@ size_t bgc_scratch_bytes(const GridView& kv, const obgc_bgc_diag* diag, bool wan
 }
 
 // carve the scratch of one launch set out of the (already reserved) arena and hook it into K
-void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
+void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool column = false) {
   const GridView& kv = K.g;
   const size_t kc1 = span_kc(kv, 1);
   auto carve = [&](size_t bytes) -> double* {
@@ -426,8 +430,16 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
   }
   const long long span1 = (long long)(kc1 / sizeof(double));
   const long long splane = (span1 + 31) & ~31LL;
-  const int nslots = K.have_diag ? (int)S_NDIAG : (int)S_NBASE;
-  K.scratch = carve((size_t)nslots * splane * sizeof(double));
+  if (column) {
+    K.scratch = nullptr;
+    K.chl100 = K.have_diag ? carve((size_t)5 * splane * sizeof(double)) : nullptr;
+    K.jw = K.have_diag ? K.chl100 + splane : nullptr;
+    K.jsed = K.have_diag ? carve((size_t)3 * kv.ncol * sizeof(double)) : nullptr;
+  } else {
+    const int nslots = K.have_diag ? (int)S_NDIAG : (int)S_NBASE;
+    K.scratch = carve((size_t)nslots * splane * sizeof(double));
+    K.chl100 = K.have_diag ? K.scratch + (long long)S_CHL100 * splane : nullptr;
+  }
   K.splane = splane;
   if (K.have_diag) {
     const size_t zbytes = (size_t)(3 * kv.plane + span1) * sizeof(double);
@@ -444,7 +456,41 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat) {
 // OBGC_SCHED picks when the carbonate kernel is released: 1 (default) when the cell kernel ends, so that its
 // fp64 work overlaps the memory-bound sweep and the cell kernel has the register file to itself; 0 at t = 0;
 // 2 = solved inside the cell kernel's wavefronts (measured slower: two waves per SIMD cannot feed the VALU).
+// The native layout's default: the column-block kernel (attenuation, scan, cell terms and sweep in one launch) on s_main
+// with the carbonate kernel beside it on s_aux from the start (schedule 4: the column kernel leaves VALU issue slots idle
+// while it waits on its stores, 47.7 ms against 51 ms at 1 M columns x 80 levels), then the saturation-horizon scan and
+// the column integrals, which read what the two wrote.  OBGC_SCHED = 1 starts the carbonate kernel when the column kernel
+// ends; OBGC_SCHED = 2 solves the carbonate system inside the column kernel's wavefronts (schedule 3).
+int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F) {
+  const int fuse = (h->sched == 2) ? 1 : 0;
+  h->last_sched = fuse ? 3 : 4;
+  FusedParams fp;
+  fp.dms = h->dms;
+  fp.macros = h->macros;
+  HIP_TRY(h, hipEventRecord(h->ev_e0, h->s_main));
+  HIP_TRY(h, hipEventRecord(h->ev_k0, h->s_main));
+  launch_bgc_column(K, h->bgc, F, F ? &fp : nullptr, h->s_main, fuse);
+  HIP_TRY(h, hipEventRecord(h->ev_k1, h->s_main));
+  h->cell_valid = true;
+  HIP_TRY(h, hipStreamWaitEvent(h->s_aux, (fuse || h->sched == 1) ? h->ev_k1 : h->ev_e0, 0));
+  HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
+  if (!fuse) launch_bgc_carbonate(K, h->bgc, h->s_aux);
+  HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
+  if (want_zsat) launch_bgc_zsat(K, h->s_aux);
+  HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_aux2, h->ev_k1, 0));   // zint reads the column kernel's profiles
+  launch_bgc_zint(K, h->bgc, h->s_aux2);
+  HIP_TRY(h, hipEventRecord(h->ev_aux2_done, h->s_aux2));
+  HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
+  HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux2_done, 0));
+  return OBGC_OK;
+}
+
 int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F = nullptr) {
+  // the scratch was carved for one form or the other (bgc_carve_scratch): the column-block kernel has no hand-off planes
+  if (!K.g.kfast && K.scratch == nullptr) return bgc_launch_column(h, K, want_zsat, F);
+  if (K.scratch == nullptr) return fail(h, OBGC_ERR_INVALID, "internal: the separate kernels were launched without their hand-off planes");
   // Large batches with diagnostics: the sweep (one wave per SIMD) is the longest kernel of the last phase and a
   // carbonate kernel beside it only slows it down (13.5 ms against 6.9 ms alone at 1 M columns), so the carbonate system
   // is solved inside the cell kernel's wavefronts instead: -4 % at 200 k - 1 M columns, +3 % at 100 k (measured).
@@ -500,6 +546,7 @@ int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, b
     Kt.g.ncol = nc;
     Kt.tracers += off; Kt.temp += off; Kt.salt += off; Kt.zmid += off; Kt.dz += off; Kt.zbot += off; Kt.fesed += off;
     Kt.tend += off; Kt.ph_prev += off; Kt.ph_prev_alt += off; Kt.scratch += off;
+    if (Kt.chl100) Kt.chl100 += off;
     Kt.lat += c0; Kt.kmax += c0; Kt.dust += c0; Kt.sw += c0;
     if (Kt.co3_out) { Kt.co3_out += off; Kt.sat_calc_out += off; Kt.sat_arag_out += off; }
     if (Kt.z_photoC) { Kt.z_photoC += off; Kt.z_photoC_NO3 += off; Kt.z_CaCO3_form += off; Kt.z_bSi_form += off; }
@@ -788,7 +835,8 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   }
   obgc_bgc_diag wdiag0;                   // hybrid: the workspace owns every level-dependent plane it uses
   std::memset(&wdiag0, 0, sizeof wdiag0);
-  size_t scratch = bgc_scratch_bytes(kv, a->diag, want_zsat, tiled);
+  const bool column = !tiled && !v.kfast && h->column;   // generic strides (OBGC_KFAST_DIRECT=1) keep the separate kernels
+  size_t scratch = bgc_scratch_bytes(kv, a->diag, want_zsat, tiled, column);
   if (hybrid) {
     work = align_up(tplane * (size_t)(30 + 5 + 30 + 27));
     scratch = bgc_scratch_bytes(v, a->diag, want_zsat, false) + bgc_scratch_bytes(kv, a->diag ? &wdiag0 : nullptr, want_zsat, true);
@@ -816,7 +864,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
 
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
   if (!tiled) {
-    bgc_carve_scratch(h, K, want_zsat);
+    bgc_carve_scratch(h, K, want_zsat, column);
     rc = bgc_launch(h, K, want_zsat);
     if (rc != OBGC_OK) return rc;
   } else if (hybrid) {
@@ -880,7 +928,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
         if (it->caller == dd.POC_ACCUM || it->caller == dd.DONr_remin || it->caller == dd.DOPr_remin) it = outs.erase(it);
         else ++it;
     }
-    bgc_carve_scratch(h, T, want_zsat);
+    bgc_carve_scratch(h, T, want_zsat, h->column != 0);   // (sized for the separate kernels, which need more)
     const size_t arena_mark = h->arena_used;
     (void)arena_mark;
     HIP_TRY(h, hipEventRecord(h->ev_t0, h->s_main));
@@ -945,8 +993,10 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   h->cell_valid = false;
   const bool want_zsat = b.diag && (b.diag->zsatcalc || b.diag->zsatarag);
   const size_t kc1 = span_kc(v, 1);
-  const size_t dms_scratch = a->dms ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
-  int rc = arena_reserve(h, bgc_scratch_bytes(v, b.diag, want_zsat, false) + dms_scratch);
+  // (the column-block kernel needs none of it: DMS's light runs through LDS beside BGC's)
+  const size_t dms_scratch = (a->dms && !h->column) ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
+  const bool column = h->column != 0;
+  int rc = arena_reserve(h, bgc_scratch_bytes(v, b.diag, want_zsat, false, column) + dms_scratch);
   if (rc != OBGC_OK) return rc;
 
   BgcKernelArgs K;
@@ -959,7 +1009,7 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   if (b.diag) K.diag = *b.diag;
   K.have_diag = b.diag ? 1 : 0;
   K.alt_co2_use_eco = b.alt_co2_use_eco;
-  bgc_carve_scratch(h, K, want_zsat);
+  bgc_carve_scratch(h, K, want_zsat, column);
 
   FusedDmArgs F;
   std::memset(&F, 0, sizeof F);
@@ -969,7 +1019,7 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   if (a->prot && a->macros_diag) { F.mdiag = *a->macros_diag; F.have_mdiag = 1; }
   F.f_qsw_par_dms = h->dms.f_qsw_par_DMS;
   F.all_flagged = (h->dms.f_qsw_par_DMS != 0.45) ? 1 : 0;   // BGC's f_qsw_par is the constant 0.45 (BGC_parms.F90:454-455)
-  if (a->dms) {
+  if (a->dms && !column) {
     auto carve = [&](size_t bytes) -> void* {
       void* p = h->arena + h->arena_used;
       h->arena_used += align_up(bytes);

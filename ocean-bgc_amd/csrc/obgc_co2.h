@@ -356,25 +356,58 @@ __device__ __forceinline__ void comp_co3_sat_vals(bool deep, double depth, doubl
 // One cell of the interior carbonate block (BGC_mod.F90:935-1001): constants, the two [H+] solves, species,
 // saturation values, PH_PREV_* update.  Every lane of the wavefront must call it (the solver votes with
 // wavefront ballots); `inside` = the lane maps to a cell of the grid at all.
-__device__ __forceinline__ void carbonate_cell(const BgcKernelArgs& A, int i_dic, int i_alk, int i_po4, int i_sio3, bool inside,
-                                               int k, int c) {
+// the inputs of one cell's carbonate block, as values
+struct CarbIn {
+  bool live;
+  long long ix;
+  double T, S, zmid, dic, alk, po4, sio3, php, pha;   // raw
+};
+
+__device__ __forceinline__ void carbonate_load(const BgcKernelArgs& A, int i_dic, int i_alk, int i_po4, int i_sio3, bool inside, int k,
+                                               int c, CarbIn& in) {
   const GridView& g = A.g;
   const int kmax = inside ? A.kmax[c] : 0;
-  const bool live = inside && k < kmax;
-  const long long ix = inside ? g.at(k, c) : 0;
+  in.live = inside && k < kmax;
+  in.ix = inside ? g.at(k, c) : 0;
+  const long long ix = in.ix;
+  in.T = 10.0; in.S = 35.0; in.zmid = 0.0; in.dic = 2000.0; in.alk = 2300.0; in.po4 = 0.0; in.sio3 = 0.0; in.php = 0.0; in.pha = 0.0;
+  if (in.live) {
+    in.T = A.temp[ix];
+    in.S = A.salt[ix];
+    in.zmid = A.zmid[ix];
+    in.dic = A.tracers[(long long)(i_dic - 1) * g.plane + ix];
+    in.alk = A.tracers[(long long)(i_alk - 1) * g.plane + ix];
+    in.po4 = A.tracers[(long long)(i_po4 - 1) * g.plane + ix];
+    in.sio3 = A.tracers[(long long)(i_sio3 - 1) * g.plane + ix];
+    in.php = A.ph_prev[ix];
+    in.pha = A.ph_prev_alt[ix];
+  }
+}
 
+__device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool inside, int k, const CarbIn& in);
+
+__device__ __forceinline__ void carbonate_cell(const BgcKernelArgs& A, int i_dic, int i_alk, int i_po4, int i_sio3, bool inside,
+                                               int k, int c) {
+  CarbIn in;
+  carbonate_load(A, i_dic, i_alk, i_po4, i_sio3, inside, k, c, in);
+  carbonate_solve(A, inside, k, in);
+}
+
+__device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool inside, int k, const CarbIn& in) {
+  const bool live = in.live;
+  const long long ix = in.ix;
   double T = 10.0, S = 35.0, depth = 0.0, dic = 2000.0, alk = 2300.0, po4 = 0.0, sio3 = 0.0;
   double php = 0.0, pha = 0.0;
   if (live) {
-    T = A.temp[ix];
-    S = A.salt[ix];
-    depth = A.zmid[ix] * 0.01;                                   // cm -> m, BGC_mod.F90:950
-    dic = dmax(0.0, A.tracers[(long long)(i_dic - 1) * g.plane + ix]);   // clamps of 747-752
-    alk = dmax(0.0, A.tracers[(long long)(i_alk - 1) * g.plane + ix]);
-    po4 = dmax(0.0, A.tracers[(long long)(i_po4 - 1) * g.plane + ix]);
-    sio3 = dmax(0.0, A.tracers[(long long)(i_sio3 - 1) * g.plane + ix]);
-    php = A.ph_prev[ix];
-    pha = A.ph_prev_alt[ix];
+    T = in.T;
+    S = in.S;
+    depth = in.zmid * 0.01;                                      // cm -> m, BGC_mod.F90:950
+    dic = dmax(0.0, in.dic);                                     // clamps of 747-752
+    alk = dmax(0.0, in.alk);
+    po4 = dmax(0.0, in.po4);
+    sio3 = dmax(0.0, in.sio3);
+    php = in.php;
+    pha = in.pha;
   }
   const bool deep = k > 0;   // reference level index k > 1
   if (__ballot(live) == 0ull) {

@@ -39,7 +39,7 @@ __device__ __forceinline__ void dms_cell_terms(const obgc_dms_params& P, const o
                                                double DMS, double DMSP, double zooC, double spC, double spCaCO3, double diatC,
                                                double diazC, double phaeoC, double spChl, double PAR_avg, double& t_dms,
                                                double& t_dmsp) {
-#define ST(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
+#define ST(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
   const double k_S_p = P.k_S_p_base * (P.mort + (zooC / 0.3));          // 529: hard-wired 0.3, not zooC_avg
   const double j_dms = P.j_dms_perI * PAR_avg;
   // community partition (570-612)

@@ -27,6 +27,9 @@
 // re-associates (Fe, SiO3, PO4: the per-autotroph terms are folded before the particle terms
 // are added) and P_iron production (Fe scavenging added last); the change is a few ulp of the
 // largest term, far inside the parity bar, and is listed in DESIGN.md.
+#include <cstdio>
+#include <cstring>
+
 #include "obgc_co2.h"
 #include "obgc_dm.h"
 
@@ -255,55 +258,215 @@ __device__ __forceinline__ double pick_Chl(const Pool1 (&r)[4], int a) {
   return a == 0 ? r[0].Chl : (a == 1 ? r[1].Chl : (a == 2 ? r[2].Chl : r[3].Chl));
 }
 
+struct Flux { double s, h; };   // soft / hard sub-class flux leaving a level
+
+// Everything one level of the sweep reads.  The loads do not depend on the recurrence, so the next level's
+// set is requested before the current level is evaluated (one wave per SIMD cannot hide HBM latency any
+// other way: 100k columns are only 1 563 wavefronts).
+template <bool DIAG>
+struct LevelIn {
+  double dz, zb, fesed, T, NO3, Fe, O2;
+  double prodPOC, prodCa, prodSi, PfeLoc;
+  double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_alk, L_o2;
+  double oc0, d0, jc, jn, jp, jsi;   // DIAG only
+};
+
+// Dissolution length scales and decay factors across one level (2273-2339): cell-local functions of zbot, T, O2 and dz.
+// TfuncS = Q_10 ** (((T + T0) - (Tref + T0)) / 10), the same number the ecosystem terms use.
+struct LevelDerived {
+  double poc_diss, sio2_diss, caco3_diss;
+  double decay_POC_E, decay_SiO2, decay_CaCO3, decay_dust, DECAY_Hard, DECAY_HardDust;
+};
+
+__device__ __forceinline__ LevelDerived derive_level(const obgc_bgc_params& P, double zb, double TfuncS, double O2, double dz) {
+  double scalelength;
+  {
+    const double* sz = P.parm_scalelen_z;
+    const double* sv = P.parm_scalelen_vals;
+    if (zb < sz[0]) scalelength = sv[0];
+    else if (zb >= sz[3]) scalelength = sv[3];
+    else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
+    else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
+    else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
+  }
+  double poc_diss = P.parm_POC_diss;
+  if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
+  else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
+  poc_diss = scalelength * poc_diss;
+  double sio2_diss = scalelength * P.parm_SiO2_diss;
+  const double caco3_diss = scalelength * P.parm_CaCO3_diss;
+  const double dust_diss = scalelength * DUST_DISS;
+  sio2_diss = sio2_diss / TfuncS;
+  LevelDerived d;
+  d.poc_diss = poc_diss; d.sio2_diss = sio2_diss; d.caco3_diss = caco3_diss;
+  d.decay_POC_E = exp(-dz / poc_diss); d.decay_SiO2 = exp(-dz / sio2_diss); d.decay_CaCO3 = exp(-dz / caco3_diss);
+  d.decay_dust = exp(-dz / dust_diss); d.DECAY_Hard = exp(-dz / 4.0e6); d.DECAY_HardDust = exp(-dz / 1.2e7);
+  return d;
+}
+
+// ---- the column-block kernel's view of a cell (bgc_column_kernel below) ----
+// A workgroup of kColLevels wavefronts owns 64 columns; wavefront w evaluates level 4 j + w of chunk j, lane = column.
+constexpr int kColLevels = 4;
+constexpr int kColThreads = 64 * kColLevels;
+
+// Hand-off of a cell to the wavefront that walks the column and back (LDS, one fp64 slot per lane and quantity).  The
+// same 29 slots serve, one after the other, as the cell terms' own scratch (20 masked pools + 9 prologue results), as the
+// inputs of the recurrence (H_IN_*), and as its results for the cell's finishing arithmetic (H_OUT_*: the walking lane
+// reads a cell's inputs into registers before it writes that cell's results).
+enum HandoffSlot {
+  H_DZ, H_ZB, H_FESED, H_NO3, H_FE, H_O2,
+  H_POC_DISS, H_SIO2_DISS, H_CACO3_DISS, H_DEC_POC, H_DEC_SI, H_DEC_CA, H_DEC_DUST, H_DEC_HARD, H_DEC_HARDDUST,
+  H_PRODPOC, H_PRODCA, H_PRODSI, H_PFELOC,
+  H_NIN,
+  // the local parts of the ten particle-dependent tendencies wait here for the cell's own finishing arithmetic (slots the
+  // recurrence does not touch) instead of in 20 registers across the barriers
+  H_L_NO3 = H_NIN, H_L_NH4, H_L_FE, H_L_SIO3, H_L_PO4, H_L_DONR, H_L_DOPR, H_L_DIC, H_L_ALK, H_L_O2,
+  H_NSLOTS
+};
+static_assert(H_NSLOTS == 29, "the slots also serve as the cell terms' 20 pool + 9 prologue scratch values");
+enum HandoffOutSlot {
+  H_OUT_REMINPOC, H_OUT_REMINCA, H_OUT_REMINSI, H_OUT_REMINFE, H_OUT_FESCAV, H_OUT_SEDDEN, H_OUT_OTHER,
+  H_OUT_NBASE,
+  H_OUT_INPOC = H_OUT_NBASE, H_OUT_INCA, H_OUT_INSI, H_OUT_INDUST, H_OUT_INFE, H_OUT_REMINDUST, H_OUT_FESCAVRATE, H_OUT_SEDPOC,
+  H_OUT_SEDCA, H_OUT_SEDSI, H_OUT_SEDDUST, H_OUT_SEDFE,
+  H_OUT_NDIAG
+};
+static_assert((int)H_NIN <= (int)H_NSLOTS && (int)H_OUT_NDIAG <= (int)H_NSLOTS, "hand-off values must fit the slots");
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global store the wavefront has in
+// flight (s_waitcnt vmcnt(0)) -- here that would drain ~150 diagnostic stores per lane three times per chunk, although
+// nothing another wavefront reads travels through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct ColCtx {
+  int k, c, w, lane;      // level, column, wavefront (= level within the chunk), lane (= column within the block)
+  bool valid;             // c < ncol && k < nlev; invalid lanes load from clamped addresses and only keep the barriers company
+  int parity;             // chunk parity: which PAR carry is read, which is written
+  double* ho;             // [H_N*][kColThreads]
+  double* att;            // [kColLevels][64]  exp(-KPARdz) of the chunk's levels
+  double* par;            // [2][64]           PAR entering the chunk's first level
+  double* attd;           // the same two for DMS's own light (fused step)
+  double* pard;
+};
+
 // DM: DMS_SourceSink and MACROS_SourceSink of the same cell are evaluated too (obgc_fused_step): the tracers they share
 // with BGC are in registers already, only their own five tracers are extra loads.
-template <bool DIAG, bool DM>
-__device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, const FusedParams* FP) {
+// COLK: false = cell-parallel kernel (flat cell index; light from the attenuation / scan kernels' planes; hand-off to the
+// sweep kernel through global scratch planes and parked tendencies); true = column-block kernel (cell given by X;
+// attenuation computed here and scanned down the chunk through LDS; hand-off to the sweep wavefront through LDS).
+// Everything one cell's terms read from global memory, as values.
+struct CellIn {
+  int kmax;
+  double lat, T, dz, zc, zb, fesed, salt, ztop;
+  double PO4, NO3, SiO3, NH4, Fe, O2, DOC, DON, DOFe, DOP, DOPr, DONr, zooC;   // raw tracer values
+  Pool1 raw[4];
+  double o_dms, o_dmsp, o_sst, o_spca, o_prot, o_poly, o_lip;                  // fused step: own tracers of DMS / MACROS
+  double PAR_in, KPARdz, att;                                                   // cell-parallel kernel: the light planes
+  double d_parin, d_att, d_kpardz;
+  bool dflag;                                                                   // the column has a DMS light pass of its own
+};
+
+// Every global load of a cell is issued here, back to back, before anything waits: ~45 independent requests per lane and a
+// single memory round trip per wavefront.  Cells below the sea floor load too (valid addresses, values discarded) so that
+// the kmax test does not cost a round trip of its own.  (k, c) must be inside the grid.
+template <bool DIAG, bool DM, bool COLK>
+__device__ __forceinline__ void cell_load(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, int k, int c,
+                                          CellIn& in) {
   const GridView& g = A.g;
-  const long long ncell = (long long)g.nlev * g.ncol;
-  const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
-  if (idx >= ncell) return;
-  int k, c;
-  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
-  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  const long long ix = g.at(k, c), pl = g.plane;
+  const obgc_autotroph* at = P.autotrophs;
+#define RAW(slot) A.tracers[(long long)((slot)-1) * pl + ix]
+#define SCR(s) A.scratch[(long long)(s) * A.splane + ix]
+  in.kmax = A.kmax[c];
+  in.dflag = false;
+  if (!COLK && DM && F->dms) in.dflag = F->all_flagged || F->flag[c] != 0;
+  in.lat = A.lat[c];
+  in.T = A.temp[ix]; in.dz = A.dz[ix]; in.zc = A.zmid[ix];
+  in.PO4 = RAW(P.ind[0]); in.NO3 = RAW(P.ind[1]); in.SiO3 = RAW(P.ind[2]); in.NH4 = RAW(P.ind[3]); in.Fe = RAW(P.ind[4]);
+  in.O2 = RAW(P.ind[5]); in.DOC = RAW(P.ind[9]); in.DON = RAW(P.ind[10]); in.DOFe = RAW(P.ind[11]); in.DOP = RAW(P.ind[12]);
+  in.DOPr = RAW(P.ind[13]); in.DONr = RAW(P.ind[14]); in.zooC = RAW(P.ind[15]);
+  in.PAR_in = 0.0; in.KPARdz = 1.0; in.att = 0.0;
+  if (!COLK) { in.PAR_in = SCR(S_PARIN); in.KPARdz = SCR(S_KPARDZ); in.att = SCR(S_ATT); }
+  in.zb = 0.0; in.fesed = 0.0;
+  if (COLK) { in.zb = A.zbot[ix]; in.fesed = A.fesed[ix]; }
+  in.salt = 0.0; in.ztop = 0.0;
+  if (DIAG) {
+    in.salt = A.salt[ix];
+    in.ztop = A.zbot[g.at(k > 0 ? k - 1 : 0, c)];
+    if (k == 0) in.ztop = 0.0;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) in.raw[a] = load_pool_raw(A, at[a], ix);
+  in.o_dms = in.o_dmsp = in.o_sst = in.o_spca = in.o_prot = in.o_poly = in.o_lip = 0.0;
+  in.d_parin = 0.0; in.d_att = 0.0; in.d_kpardz = 1.0;
+  if (DM) {
+    if (F->dms) { in.o_dms = F->dms[ix]; in.o_dmsp = F->dmsp[ix]; in.o_sst = F->SST[c]; in.o_spca = RAW(P.ind[19]); }
+    if (F->prot) { in.o_prot = F->prot[ix]; in.o_poly = F->poly[ix]; in.o_lip = F->lip[ix]; }
+    if (!COLK && in.dflag) { in.d_parin = F->d_parin[ix]; in.d_att = F->d_att[ix]; in.d_kpardz = F->d_kpardz[ix]; }   // last: the only dependent loads
+  }
+#undef RAW
+#undef SCR
+}
+
+// COLK only: *lo receives what the cell's finishing arithmetic needs once the recurrence has passed (the local parts of
+// the ten particle-dependent tendencies, the local parts of its diagnostics); the return value says whether this lane
+// evaluated an active cell.  `in` = the cell's loaded values (cell_load) for the cell (k, c) given here.
+template <bool DIAG, bool DM, bool COLK>
+__device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, const FusedParams* FP,
+                                          const ColCtx* X, LevelIn<DIAG>* lo, int k, int c, const CellIn& in) {
+  const GridView& g = A.g;
   const long long ix = g.at(k, c), pl = g.plane;
   const obgc_bgc_diag& D = A.diag;
   const obgc_autotroph* at = P.autotrophs;
 #define RAW(slot) A.tracers[(long long)((slot)-1) * pl + ix]
 #define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
 #define SCR(s) A.scratch[(long long)(s) * A.splane + ix]
-#define ST_KC(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
-#define ST_KCA(name, a, v) do { if (DIAG && D.name) D.name[(long long)(a) * pl + ix] = (v); } while (0)
-
-  // Every global load of the kernel is issued here, back to back, before anything waits: ~45 independent
-  // requests per lane and a single memory round trip per wavefront.  Cells below the sea floor load too (valid
-  // addresses, values discarded) so that the kmax test does not cost a round trip of its own.
-  int kmax = A.kmax[c];
-  bool dflag = false;   // this column has a DMS light pass of its own
-  if (DM && F->dms) dflag = F->all_flagged || F->flag[c] != 0;
-  const double lat = A.lat[c];
-  const double T = A.temp[ix], dz = A.dz[ix], zc = A.zmid[ix];
-  const double r_PO4 = RAW(P.ind[0]), r_NO3 = RAW(P.ind[1]), r_SiO3 = RAW(P.ind[2]), r_NH4 = RAW(P.ind[3]), r_Fe = RAW(P.ind[4]),
-               r_O2 = RAW(P.ind[5]), r_DOC = RAW(P.ind[9]), r_DON = RAW(P.ind[10]), r_DOFe = RAW(P.ind[11]), r_DOP = RAW(P.ind[12]),
-               r_DOPr = RAW(P.ind[13]), r_DONr = RAW(P.ind[14]), r_zooC = RAW(P.ind[15]);
-  const double PAR_in = SCR(S_PARIN), KPARdz = SCR(S_KPARDZ), att = SCR(S_ATT);
-  double r_salt = 0.0, ztop = 0.0;
-  if (DIAG) {
-    r_salt = A.salt[ix];
-    ztop = A.zbot[g.at(k > 0 ? k - 1 : 0, c)];
-    if (k == 0) ztop = 0.0;
-  }
-  Pool1 raw[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) raw[a] = load_pool_raw(A, at[a], ix);
-  double o_dms = 0.0, o_dmsp = 0.0, o_sst = 0.0, o_spca = 0.0, o_prot = 0.0, o_poly = 0.0, o_lip = 0.0;
-  double d_parin = 0.0, d_att = 0.0, d_kpardz = 1.0;
-  if (DM) {
-    if (F->dms) { o_dms = F->dms[ix]; o_dmsp = F->dmsp[ix]; o_sst = F->SST[c]; o_spca = RAW(P.ind[19]); }
-    if (F->prot) { o_prot = F->prot[ix]; o_poly = F->poly[ix]; o_lip = F->lip[ix]; }
-    if (dflag) { d_parin = F->d_parin[ix]; d_att = F->d_att[ix]; d_kpardz = F->d_kpardz[ix]; }   // last: the only dependent loads
-  }
+#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
+#define ST_KCA(name, a, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[(long long)(a) * pl + ix], (v)); } while (0)
+  int kmax = in.kmax;
+  bool dflag = in.dflag;
+  const double lat = in.lat, T = in.T, dz = in.dz, zc = in.zc;
+  const double r_PO4 = in.PO4, r_NO3 = in.NO3, r_SiO3 = in.SiO3, r_NH4 = in.NH4, r_Fe = in.Fe, r_O2 = in.O2, r_DOC = in.DOC,
+               r_DON = in.DON, r_DOFe = in.DOFe, r_DOP = in.DOP, r_DOPr = in.DOPr, r_DONr = in.DONr, r_zooC = in.zooC;
+  double PAR_in = in.PAR_in, KPARdz = in.KPARdz, att = in.att;
+  const double zb = in.zb, r_fesed = in.fesed, r_salt = in.salt, ztop = in.ztop;
+  const Pool1 raw[4] = {in.raw[0], in.raw[1], in.raw[2], in.raw[3]};
+  const double o_dms = in.o_dms, o_dmsp = in.o_dmsp, o_sst = in.o_sst, o_spca = in.o_spca, o_prot = in.o_prot, o_poly = in.o_poly,
+               o_lip = in.o_lip;
+  double d_parin = in.d_parin, d_att = in.d_att, d_kpardz = in.d_kpardz;
   if (kmax > g.nlev) kmax = g.nlev;
+
+  if (COLK) {
+    // Light (BGC_mod.F90:907-924): the attenuation of this level from the masked chlorophyll, then the product down the
+    // chunk's levels in the reference's order: PAR entering level w = ((carry * att_0) * att_1) ... * att_(w-1).
+    const int w = X->w, lane = X->lane;
+    double chl[4], chl0[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { chl[a] = mask_pool(at[a], raw[a]).Chl; chl0[a] = dmax(0.0, raw[a].Chl); }
+    KPARdz = kpar_dz(chl, dz);
+    att = exp(-KPARdz);
+    X->att[w * 64 + lane] = att;
+    if (DM && F->dms) {
+      // DMS attenuates with the clamped, unmasked chlorophyll and its own PAR fraction (DMS_mod.F90:506-507, 539-550): the
+      // same numbers as BGC's unless the mask removed a pool with chlorophyll left in it
+      d_kpardz = KPARdz; d_att = att;
+      if (dms_total_chl(chl0, P) != sum4(chl)) { d_kpardz = kpar_dz_of(dms_total_chl(chl0, P), dz); d_att = exp(-d_kpardz); }
+      X->attd[w * 64 + lane] = d_att;
+    }
+    lds_barrier();
+    double PAR = X->par[X->parity * 64 + lane];
+    for (int j = 0; j < w; ++j) PAR = PAR * X->att[j * 64 + lane];
+    PAR_in = PAR;
+    if (w == kColLevels - 1) X->par[(X->parity ^ 1) * 64 + lane] = PAR_in * att;
+    if (DM && F->dms) {
+      double PARd = X->pard[X->parity * 64 + lane];
+      for (int j = 0; j < w; ++j) PARd = PARd * X->attd[j * 64 + lane];
+      d_parin = PARd;
+      if (w == kColLevels - 1) X->pard[(X->parity ^ 1) * 64 + lane] = PARd * d_att;
+      dflag = true;   // DMS always takes its own (usually identical) numbers here
+    }
+    if (!X->valid) return false;
+  }
 
   if (k >= kmax) {
     // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727; DMS_mod.F90:413,
@@ -331,7 +494,7 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
       ZKCA(bSi_form) ZKCA(CaCO3_form) ZKCA(Nfix)
 #undef ZKCA
     }
-    return;
+    return false;
   }
 
   const double T0K = P.T0_Kelvin_BGC;
@@ -374,8 +537,11 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   // wait for every one of them to be acknowledged.  From here on the kernel only stores.
   //   DOM remineralisation (1436-1461), nitrification (1554-1561), the O2 weights of denitrification and
   //   O2 consumption (1569-1577, 1784-1790), AOU, the 100 m weight of the Chl integral
-  __shared__ double s_tail[9][kBlockCell];
+  constexpr int NT = COLK ? kColThreads : kBlockCell;
+  __shared__ double s_tail_own[COLK ? 1 : 9][COLK ? 1 : kBlockCell];
   const int tid = threadIdx.x;
+  // the column-block kernel lends its hand-off slots: pools in slots 0..19, prologue results in 20..28
+  double (*s_tail)[NT] = COLK ? (double (*)[NT])(X->ho + 20 * NT) : (double (*)[NT])s_tail_own;
   double aou = 0.0;
   {
     const double O2 = dmax(0.0, r_O2), DOC = dmax(0.0, r_DOC), DON = dmax(0.0, r_DON), DOFe = dmax(0.0, r_DOFe),
@@ -423,7 +589,8 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   // ---- pre-pass: Pprime (1072-1094), grazing (1297-1324), zooplankton losses (1395-1415) ----
   // The masked pools are read from HBM once and parked in LDS for the rolled loop below (each lane only
   // ever touches its own column of the array, so no barrier is needed).
-  __shared__ double s_pool[20][kBlockCell];
+  __shared__ double s_pool_own[COLK ? 1 : 20][COLK ? 1 : kBlockCell];
+  double (*s_pool)[NT] = COLK ? (double (*)[NT])X->ho : (double (*)[NT])s_pool_own;
   double Pprime[4], graze[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -654,7 +821,9 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
                wo = s_tail[8][tid];
   const double prodPOC = f_zoo_detr * zoo_loss + s_gr_poc + s_agg + s_ls_poc;        // 1467-1468
 
-  SCR(S_PRODPOC) = prodPOC; SCR(S_PRODCA) = prodCa; SCR(S_PRODSI) = prodSi; SCR(S_PFELOC) = PfeLoc;
+  double (*ho)[NT] = COLK ? (double (*)[NT])X->ho : nullptr;   // written below: every read of s_tail / s_pool is done
+  if (COLK) { ho[H_PRODPOC][tid] = prodPOC; ho[H_PRODCA][tid] = prodCa; ho[H_PRODSI][tid] = prodSi; ho[H_PFELOC][tid] = PfeLoc; }
+  else { SCR(S_PRODPOC) = prodPOC; SCR(S_PRODCA) = prodCa; SCR(S_PRODSI) = prodSi; SCR(S_PFELOC) = PfeLoc; }
 
   // ---- local parts of denitrification (1569-1577) and O2 consumption (1784-1790): the terms that do not
   //      involve the particle remineralisation, weighted in the prologue; the sweep adds  w * (remin terms)  ----
@@ -674,16 +843,31 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
   TEND(P.ind[12]) = t_dop;
   // ---- particle-dependent tendencies: everything local is folded here and waits in the caller's
   //      tendency plane; the sweep adds the remineralisation terms (listed with each line) ----
-  TEND(P.ind[1]) = (NITRIF - sNO3V) - D0;                                             // 1583: - wd*((reminPOC-OTHER)/C - SED) - SED
-  TEND(P.ind[3]) = ((-sNH4V - NITRIF + DON_remin + DONr_remin) + QN * S3) + nexc;     // 1585-1592: + QN*(1-DONrefract)*reminPOC
-  TEND(P.ind[4]) = ((QFE_ZOO * zoo_loss_dic) + DOFe_remin - sPhotoFe) + L_fe_a;       // 1598-1605: + reminFe - Fe_scavenge
-  TEND(P.ind[2]) = L_sio3_a;                                                          // 1620-1628: + reminSi
-  TEND(P.ind[0]) = ((DOP_remin + DOPr_remin - sPO4V) + L_po4_a) + QP_ZOO_POM * zoo_loss_dic;   // 1643-1661: + Qp*(1-DOPrefract)*reminPOC
-  TEND(P.ind[14]) = (DON_prod * DONREFRACT) - DONr_remin;                             // 1714: + reminPOC*DONrefract*Q
-  TEND(P.ind[13]) = (DOP_prod * DOPREFRACT) - DOPr_remin;                             // 1720: + reminPOC*DOPrefract*Qp
-  TEND(P.ind[6]) = ((s_ls_dic + s_gr_dic - sPhotoC + DOC_remin) + zoo_loss_dic) + CAD;   // 1729-1739: + reminPOC + reminCaCO3
-  TEND(P.ind[8]) = 2.0 * CAD;                                                         // 1749-1759: - t_no3 + t_nh4 + 2 reminCaCO3
-  TEND(P.ind[5]) = O2_PRODUCTION - OC0;                                               // 1790: - wo*(reminPOC - SED*C - OTHER)/R
+  const double L_no3 = (NITRIF - sNO3V) - D0;                                             // 1583: - wd*((reminPOC-OTHER)/C - SED) - SED
+  const double L_nh4 = ((-sNH4V - NITRIF + DON_remin + DONr_remin) + QN * S3) + nexc;     // 1585-1592: + QN*(1-DONrefract)*reminPOC
+  const double L_fe = ((QFE_ZOO * zoo_loss_dic) + DOFe_remin - sPhotoFe) + L_fe_a;        // 1598-1605: + reminFe - Fe_scavenge
+  const double L_sio3 = L_sio3_a;                                                         // 1620-1628: + reminSi
+  const double L_po4 = ((DOP_remin + DOPr_remin - sPO4V) + L_po4_a) + QP_ZOO_POM * zoo_loss_dic;   // 1643-1661: + Qp*(1-DOPrefract)*reminPOC
+  const double L_donr = (DON_prod * DONREFRACT) - DONr_remin;                             // 1714: + reminPOC*DONrefract*Q
+  const double L_dopr = (DOP_prod * DOPREFRACT) - DOPr_remin;                             // 1720: + reminPOC*DOPrefract*Qp
+  const double L_dic = ((s_ls_dic + s_gr_dic - sPhotoC + DOC_remin) + zoo_loss_dic) + CAD;   // 1729-1739: + reminPOC + reminCaCO3
+  const double L_alk = 2.0 * CAD;                                                         // 1749-1759: - t_no3 + t_nh4 + 2 reminCaCO3
+  const double L_o2 = O2_PRODUCTION - OC0;                                                // 1790: - wo*(reminPOC - SED*C - OTHER)/R
+  if (COLK) {
+    ho[H_L_NO3][tid] = L_no3; ho[H_L_NH4][tid] = L_nh4; ho[H_L_FE][tid] = L_fe; ho[H_L_SIO3][tid] = L_sio3; ho[H_L_PO4][tid] = L_po4;
+    ho[H_L_DONR][tid] = L_donr; ho[H_L_DOPR][tid] = L_dopr; ho[H_L_DIC][tid] = L_dic; ho[H_L_ALK][tid] = L_alk; ho[H_L_O2][tid] = L_o2;
+    lo->dz = dz; lo->zb = zb; lo->NO3 = NO3; lo->O2 = dmax(0.0, r_O2); lo->Fe = Fe; lo->fesed = r_fesed; lo->T = T;
+    lo->prodPOC = prodPOC; lo->prodCa = prodCa; lo->prodSi = prodSi; lo->PfeLoc = PfeLoc;
+    // what the walking wavefront would otherwise read from HBM again or compute at one lane per column
+    const LevelDerived dv = derive_level(P, zb, Tfunc, dmax(0.0, r_O2), dz);
+    ho[H_DZ][tid] = dz; ho[H_ZB][tid] = zb; ho[H_FESED][tid] = r_fesed; ho[H_NO3][tid] = NO3; ho[H_FE][tid] = Fe; ho[H_O2][tid] = dmax(0.0, r_O2);
+    ho[H_POC_DISS][tid] = dv.poc_diss; ho[H_SIO2_DISS][tid] = dv.sio2_diss; ho[H_CACO3_DISS][tid] = dv.caco3_diss;
+    ho[H_DEC_POC][tid] = dv.decay_POC_E; ho[H_DEC_SI][tid] = dv.decay_SiO2; ho[H_DEC_CA][tid] = dv.decay_CaCO3;
+    ho[H_DEC_DUST][tid] = dv.decay_dust; ho[H_DEC_HARD][tid] = dv.DECAY_Hard; ho[H_DEC_HARDDUST][tid] = dv.DECAY_HardDust;
+  } else {
+    TEND(P.ind[1]) = L_no3; TEND(P.ind[3]) = L_nh4; TEND(P.ind[4]) = L_fe; TEND(P.ind[2]) = L_sio3; TEND(P.ind[0]) = L_po4;
+    TEND(P.ind[14]) = L_donr; TEND(P.ind[13]) = L_dopr; TEND(P.ind[6]) = L_dic; TEND(P.ind[8]) = L_alk; TEND(P.ind[5]) = L_o2;
+  }
 
   if (DIAG) {
     ST_KC(NO3_RESTORE, 0.0); ST_KC(SiO3_RESTORE, 0.0); ST_KC(PO4_RESTORE, 0.0);       // lrest_* never set (131-134)
@@ -692,13 +876,12 @@ __device__ __forceinline__ void cell_body(const BgcKernelArgs& A, const obgc_bgc
     ST_KC(DOC_prod, DOC_prod); ST_KC(DOC_remin, DOC_remin); ST_KC(DON_prod, DON_prod); ST_KC(DON_remin, DON_remin);
     ST_KC(DOP_prod, DOP_prod); ST_KC(DOP_remin, DOP_remin); ST_KC(DOFe_prod, DOFe_prod); ST_KC(DOFe_remin, DOFe_remin);
     // local parts of the conservation integrals (1875-1938); the sweep adds the particle-dependent tendencies
-    SCR(S_OC0) = OC0; SCR(S_D0) = D0;
-    SCR(S_JC) = t_doc + t_zooC + sC + sCa;
-    SCR(S_JN) = t_don + QN * t_zooC + QN * sC - sNfix;
-    SCR(S_JP) = t_dop + QP_ZOO_POM * t_zooC + sQpC;
-    SCR(S_JSI) = sSi;
-    SCR(S_CHL100) = chl * pt100;
+    const double j_c = t_doc + t_zooC + sC + sCa, j_n = t_don + QN * t_zooC + QN * sC - sNfix, j_p = t_dop + QP_ZOO_POM * t_zooC + sQpC;
+    if (COLK) { lo->oc0 = OC0; lo->d0 = D0; lo->jc = j_c; lo->jn = j_n; lo->jp = j_p; lo->jsi = sSi; }
+    else { SCR(S_OC0) = OC0; SCR(S_D0) = D0; SCR(S_JC) = j_c; SCR(S_JN) = j_n; SCR(S_JP) = j_p; SCR(S_JSI) = sSi; }
+    A.chl100[ix] = chl * pt100;
   }
+  return true;
 #undef RAW
 #undef TEND
 #undef SCR
@@ -721,9 +904,24 @@ __device__ __forceinline__ void carbonate_of_this_lane(const BgcKernelArgs& A, c
   carbonate_cell(A, P.ind[6], P.ind[8], P.ind[0], P.ind[2], idx < ncell, k, c);
 }
 
+// the cell-parallel kernels' lane -> cell map: lanes run along the contiguous axis of the caller's layout
+template <bool DIAG, bool DM>
+__device__ __forceinline__ void cell_of_this_lane(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, const FusedParams* FP) {
+  const GridView& g = A.g;
+  const long long ncell = (long long)g.nlev * g.ncol;
+  const long long idx = (long long)blockIdx.x * kBlockCell + threadIdx.x;
+  if (idx >= ncell) return;
+  int k, c;
+  if (g.kfast) { k = (int)(idx % g.nlev); c = (int)(idx / g.nlev); }
+  else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
+  CellIn in;
+  cell_load<DIAG, DM, false>(A, P, F, k, c, in);
+  (void)cell_body<DIAG, DM, false>(A, P, F, FP, nullptr, nullptr, k, c, in);
+}
+
 template <bool DIAG, int FUSE>
 __global__ __launch_bounds__(kBlockCell, 2) void bgc_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
-  cell_body<DIAG, false>(A, P, nullptr, nullptr);
+  cell_of_this_lane<DIAG, false>(A, P, nullptr, nullptr);
   if (FUSE) carbonate_of_this_lane(A, P);
 }
 
@@ -734,24 +932,11 @@ static_assert(sizeof(BgcKernelArgs) + sizeof(obgc_bgc_params) + sizeof(FusedDmAr
 template <bool DIAG, int FUSE>
 __global__ __launch_bounds__(kBlockCell, 2) void fused_cell_kernel(const BgcKernelArgs A, const obgc_bgc_params P, const FusedDmArgs F,
                                                                    const FusedParams FP) {
-  cell_body<DIAG, true>(A, P, &F, &FP);
+  cell_of_this_lane<DIAG, true>(A, P, &F, &FP);
   if (FUSE) carbonate_of_this_lane(A, P);
 }
 
 // ------------------------------------------------------------------------------ particle sweep
-struct Flux { double s, h; };   // soft / hard sub-class flux leaving a level
-
-// Everything one level of the sweep reads.  The loads do not depend on the recurrence, so the next level's
-// set is requested before the current level is evaluated (one wave per SIMD cannot hide HBM latency any
-// other way: 100k columns are only 1 563 wavefronts).
-template <bool DIAG>
-struct LevelIn {
-  double dz, zb, fesed, T, NO3, Fe, O2;
-  double prodPOC, prodCa, prodSi, PfeLoc;
-  double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_alk, L_o2;
-  double oc0, d0, jc, jn, jp, jsi;   // DIAG only
-};
-
 template <bool DIAG>
 __device__ __forceinline__ void load_level(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, LevelIn<DIAG>& L) {
   const long long pl = A.g.plane, sp = A.splane;
@@ -784,6 +969,217 @@ __device__ __forceinline__ void settle(const LevelIn<DIAG>& L) {
   if (DIAG) asm volatile("" ::"v"(L.oc0), "v"(L.d0), "v"(L.jc), "v"(L.jn), "v"(L.jp), "v"(L.jsi));
 }
 
+// State the sweep carries from level to level of one column: the particle fluxes leaving the level above, the dust
+// deficit of the ballast model and (diagnostics) the conservation integrals.
+struct SweepState {
+  Flux fPOC, fCa, fSi, fFe, fDust;
+  double QA_dust_def;
+  double J[8];   // C, C above 100 m, N, N 100 m, P, P 100 m, Si, Si 100 m
+  double zbot_above;
+};
+
+// per-column initialisation (BGC_mod.F90:808-811, 2075-2104)
+__device__ __forceinline__ void sweep_init(SweepState& S, double dust_flux_in, bool has_levels) {
+  const double dust_in = has_levels ? dmax(0.0, dust_flux_in) : 0.0;
+  S.fPOC = Flux{0.0, 0.0}; S.fCa = Flux{0.0, 0.0}; S.fSi = Flux{0.0, 0.0}; S.fFe = Flux{0.0, 0.0}; S.fDust = Flux{0.0, 0.0};
+  if (dust_in != 0.0) { S.fDust.s = (1.0 - DUST_GAMMA) * dust_in; S.fDust.h = DUST_GAMMA * dust_in; }
+  S.QA_dust_def = DUST_RHO * (S.fDust.s + S.fDust.h);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) S.J[i] = 0.0;
+  S.zbot_above = 0.0;
+}
+
+// What one step of the recurrence leaves for the rest of the level's arithmetic.
+struct SweepCoreOut {
+  double reminPOC, reminCa, reminSi, reminFe, Fe_scavenge, SED_DENITRIF, OTHER_REMIN;
+  // diagnostics only
+  double inPOC, inCa, inSi, inDust, inFe, reminDust, Fe_scav_rate, sedPOC, sedCa, sedSi, sedDust, sedFe;
+};
+
+// The part of a level that really is sequential down the column: iron scavenging onto the particles entering, one step
+// of the ballast recurrence, the sea floor (BGC_mod.F90:1510-1529, 2242-2631).  ~100 flops.
+__device__ __forceinline__ void sweep_core(const obgc_bgc_params& P, bool bottom, double dz, double zb, double fesed, double NO3, double Fe,
+                                           double O2, double prodPOC, double prodCa, double prodSi, double PfeLoc, const LevelDerived& dv,
+                                           SweepState& S, SweepCoreOut& out) {
+  Flux &fPOC = S.fPOC, &fCa = S.fCa, &fSi = S.fSi, &fFe = S.fFe, &fDust = S.fDust;
+  double& QA_dust_def = S.QA_dust_def;
+  const double poc_diss = dv.poc_diss, sio2_diss = dv.sio2_diss, caco3_diss = dv.caco3_diss;
+  const double decay_POC_E = dv.decay_POC_E, decay_SiO2 = dv.decay_SiO2, decay_CaCO3 = dv.decay_CaCO3, decay_dust = dv.decay_dust,
+               DECAY_Hard = dv.DECAY_Hard, DECAY_HardDust = dv.DECAY_HardDust;
+  struct { double PfeLoc, fesed; } cur{PfeLoc, fesed};
+
+  // iron scavenging onto the particles LEAVING the level above (1510-1529)
+  double Fe_scav_rate = P.parm_fe_scavenge_rate0;
+  Fe_scav_rate = Fe_scav_rate * ((fPOC.s + fPOC.h) * 120.1 + (fCa.s + fCa.h) * CACO3_MASS + (fSi.s + fSi.h) * SIO2_MASS +
+                                 (fDust.s + fDust.h) * DUST_FESCAV_SCALE);
+  if (Fe > FE_SCAV_THRES1) Fe_scav_rate = Fe_scav_rate + (Fe - FE_SCAV_THRES1) * FE_MAX_SCALE2;
+  const double Fe_scavenge = YPS * Fe * Fe_scav_rate;
+  const double prodFe = cur.PfeLoc + Fe_scavenge;
+
+  // one step of the Armstrong et al. ballast recurrence (2242-2501)
+  const Flux inPOC = fPOC, inCa = fCa, inSi = fSi, inFe = fFe, inDust = fDust;
+  double sedPOC = 0.0, sedCa = 0.0, sedSi = 0.0, sedDust = 0.0, sedFe = 0.0, SED_DENITRIF = 0.0, OTHER_REMIN = 0.0;
+  const double dzr = 1.0 / dz;
+  fCa.s = inCa.s * decay_CaCO3 + prodCa * ((1.0 - CACO3_GAMMA) * (1.0 - decay_CaCO3) * caco3_diss);
+  fCa.h = inCa.h * DECAY_Hard + prodCa * (CACO3_GAMMA * dz);
+  fSi.s = inSi.s * decay_SiO2 + prodSi * ((1.0 - SIO2_GAMMA) * (1.0 - decay_SiO2) * sio2_diss);
+  fSi.h = inSi.h * DECAY_Hard + prodSi * (SIO2_GAMMA * dz);
+  fDust.s = inDust.s * decay_dust;
+  fDust.h = inDust.h * DECAY_HardDust;
+  double POC_PROD_avail = prodPOC - CACO3_RHO * prodCa - SIO2_RHO * prodSi;
+  double new_def = (QA_dust_def > 0) ? QA_dust_def * (fDust.s + fDust.h) / (inDust.s + inDust.h) : 0.0;
+  if (new_def > 0.0) {
+    new_def = new_def - POC_PROD_avail * dz;
+    if (new_def < 0.0) { POC_PROD_avail = -new_def * dzr; new_def = 0.0; }
+    else POC_PROD_avail = 0.0;
+  }
+  QA_dust_def = new_def;
+  if (inPOC.h == 0.0 && prodPOC == 0.0) {
+    fPOC.h = 0.0;
+  } else {
+    fPOC.h = CACO3_RHO * (fCa.s + fCa.h) + SIO2_RHO * (fSi.s + fSi.h) + DUST_RHO * (fDust.s + fDust.h) - new_def;
+    fPOC.h = dmax(fPOC.h, 0.0);
+  }
+  fPOC.s = inPOC.s * decay_POC_E + POC_PROD_avail * ((1.0 - decay_POC_E) * poc_diss);
+  double reminCa = prodCa + ((inCa.s - fCa.s) + (inCa.h - fCa.h)) * dzr;
+  double reminSi = prodSi + ((inSi.s - fSi.s) + (inSi.h - fSi.h)) * dzr;
+  double reminPOC = prodPOC + ((inPOC.s - fPOC.s) + (inPOC.h - fPOC.h)) * dzr;
+  const double reminDust = ((inDust.s - fDust.s) + (inDust.h - fDust.h)) * dzr;
+  double reminFe;
+  if (inPOC.s + inPOC.h == 0.0) reminFe = (reminPOC * RED_FE_C);
+  else reminFe = (reminPOC * (inFe.s + inFe.h) / (inPOC.s + inPOC.h));
+  reminFe = reminFe + (inFe.s * 1.5e-5);
+  fFe.s = inFe.s + dz * ((1.0 - 0.0) * prodFe - reminFe);
+  if (fFe.s < 0.0) {
+    fFe.s = 0.0;
+    reminFe = inFe.s * dzr + (1.0 - 0.0) * prodFe;
+  }
+  reminFe = reminFe + reminDust * DUST_TO_FE + (cur.fesed * dzr);
+  fFe.h = inFe.h;
+
+  if (bottom) {   // sea floor: burial, sediment denitrification, instantaneous remin (2522-2631)
+    double flux = fPOC.s + fPOC.h, flux_alt;
+    if (flux > 0.0) {
+      flux_alt = flux * 0.01 * SPD;
+      sedPOC = flux * dmin(0.8, P.parm_POMbury * (0.013 + 0.53 * flux_alt * flux_alt / ((7.0 + flux_alt) * (7.0 + flux_alt))));
+      SED_DENITRIF = dzr * flux * (0.06 + 0.19 * exp((O2 - NO3) * LN_0_99));   // 0.99 ** (O2 - NO3)
+      if (NO3 < 5.0) SED_DENITRIF = 0.0;
+      flux_alt = flux * 1.0e-6 * SPD * 365.0;
+      OTHER_REMIN = dzr * dmin(dmin(0.1 + flux_alt, 0.5) * (flux - sedPOC), (flux - sedPOC - (SED_DENITRIF * dz * DENITRIF_C_N)));
+      if (O2 < 1.0) OTHER_REMIN = dzr * (flux - sedPOC - (SED_DENITRIF * dz * DENITRIF_C_N));
+    }
+    flux = fSi.s + fSi.h;
+    flux_alt = flux * 0.01 * SPD;
+    sedSi = (flux_alt > 2.0) ? 0.2 : 0.04;
+    sedSi = flux * P.parm_BSIbury * sedSi;
+    if (zb < 3300.0e2) sedCa = fCa.s + fCa.h;
+    flux = fCa.s + fCa.h;
+    if (flux > 0.0) reminCa = reminCa + ((flux - sedCa) * dzr);
+    flux = fSi.s + fSi.h;
+    if (flux > 0.0) reminSi = reminSi + ((flux - sedSi) * dzr);
+    flux = fPOC.s + fPOC.h;
+    if (flux > 0.0) reminPOC = reminPOC + ((flux - sedPOC) * dzr);
+    flux = (fFe.s + fFe.h);
+    if (flux > 0.0) sedFe = flux;
+    sedDust = fDust.s + fDust.h;
+    fCa = Flux{0.0, 0.0}; fSi = Flux{0.0, 0.0}; fDust = Flux{0.0, 0.0}; fPOC = Flux{0.0, 0.0}; fFe = Flux{0.0, 0.0};
+  }
+
+  out.reminPOC = reminPOC; out.reminCa = reminCa; out.reminSi = reminSi; out.reminFe = reminFe; out.Fe_scavenge = Fe_scavenge;
+  out.SED_DENITRIF = SED_DENITRIF; out.OTHER_REMIN = OTHER_REMIN;
+  out.inPOC = inPOC.s + inPOC.h; out.inCa = inCa.s + inCa.h; out.inSi = inSi.s + inSi.h; out.inDust = inDust.s + inDust.h;
+  out.inFe = inFe.s + inFe.h; out.reminDust = reminDust; out.Fe_scav_rate = Fe_scav_rate;
+  out.sedPOC = sedPOC; out.sedCa = sedCa; out.sedSi = sedSi; out.sedDust = sedDust; out.sedFe = sedFe;
+}
+
+// The integrands of the conservation integrals of one level (BGC_mod.F90:1870-1938): the local parts from the cell terms plus
+// the tendencies finished with the particle terms.
+struct JTerms { double C, N, P, Si; };
+
+// The rest of the level, cell-local once the recurrence has passed: denitrification, the particle-dependent part of 11
+// tendencies and 27 diagnostics (1569-1577, 1583-1790, 2637-2694).  Stores go to the caller's arrays at index ix.
+template <bool DIAG>
+__device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, const LevelIn<DIAG>& cur,
+                                               const SweepCoreOut& o) {
+  const obgc_bgc_diag& D = A.diag;
+  const long long pl = A.g.plane;
+#define TEND(slot, ix) A.tend[(long long)((slot)-1) * pl + (ix)]
+#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
+  const double dz = cur.dz, NO3 = dmax(0.0, cur.NO3), O2 = dmax(0.0, cur.O2);
+  const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
+  const double reminPOC = o.reminPOC, reminCa = o.reminCa, reminSi = o.reminSi, reminFe = o.reminFe, Fe_scavenge = o.Fe_scavenge,
+               SED_DENITRIF = o.SED_DENITRIF, OTHER_REMIN = o.OTHER_REMIN;
+  // ---- denitrification (1569-1577) and the particle-dependent tendencies (1583-1790): the cell kernel
+  //      left every local term in the tendency planes; only the remineralisation terms are added here ----
+  double wd = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
+  wd = dmin(dmax(wd, 0.0), 1.0);
+  if (NO3 == 0.0) wd = 0.0;
+  const double den_p = wd * ((reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
+  const double t_no3 = (cur.L_no3 - den_p) - SED_DENITRIF;
+  const double t_nh4 = cur.L_nh4 + QN * (reminPOC * (1.0 - DONREFRACT));
+  const double t_fe = (reminFe + cur.L_fe) - Fe_scavenge;
+  const double t_sio3 = reminSi + cur.L_sio3;
+  const double t_po4 = cur.L_po4 + QP_ZOO_POM * ((1.0 - DOPREFRACT) * reminPOC);
+  const double t_donr = cur.L_donr + (reminPOC * DONREFRACT * QN);
+  const double t_dopr = cur.L_dopr + (reminPOC * DOPREFRACT * QP_ZOO_POM);
+  const double t_dic = (cur.L_dic + reminPOC) + reminCa;
+  const double t_alk = (-t_no3 + t_nh4 + 2.0 * reminCa) + cur.L_alk;
+  double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
+  wo = dmin(dmax(wo, 0.0), 1.0);
+  const double oc_p = wo * ((reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN) / REMIN_D_C_O2);
+  TEND(P.ind[1], ix) = t_no3;
+  TEND(P.ind[3], ix) = t_nh4;
+  TEND(P.ind[4], ix) = t_fe;
+  TEND(P.ind[2], ix) = t_sio3;
+  TEND(P.ind[0], ix) = t_po4;
+  TEND(P.ind[14], ix) = t_donr;
+  TEND(P.ind[13], ix) = t_dopr;
+  TEND(P.ind[6], ix) = t_dic;
+  TEND(P.ind[7], ix) = A.alt_co2_use_eco ? t_dic : 0.0;
+  TEND(P.ind[8], ix) = t_alk;
+  TEND(P.ind[5], ix) = cur.L_o2 - oc_p;
+
+  JTerms jt{0.0, 0.0, 0.0, 0.0};
+  if (DIAG) {   // 2637-2694, 1563-1577, 1866-1868
+    ST_KC(POC_FLUX_IN, o.inPOC); ST_KC(POC_PROD, prodPOC); ST_KC(POC_REMIN, reminPOC);
+    ST_KC(CaCO3_FLUX_IN, o.inCa); ST_KC(CaCO3_PROD, prodCa); ST_KC(CaCO3_REMIN, reminCa);
+    ST_KC(SiO2_FLUX_IN, o.inSi); ST_KC(SiO2_PROD, prodSi); ST_KC(SiO2_REMIN, reminSi);
+    ST_KC(dust_FLUX_IN, o.inDust); ST_KC(dust_REMIN, o.reminDust);
+    ST_KC(P_iron_FLUX_IN, o.inFe); ST_KC(P_iron_PROD, cur.PfeLoc + Fe_scavenge); ST_KC(P_iron_REMIN, reminFe);
+    ST_KC(calcToSed, o.sedCa); ST_KC(bsiToSed, o.sedSi); ST_KC(pocToSed, o.sedPOC);
+    ST_KC(SedDenitrif, SED_DENITRIF * dz); ST_KC(OtherRemin, OTHER_REMIN * dz);
+    ST_KC(ponToSed, (o.sedPOC * QN)); ST_KC(popToSed, (o.sedPOC * QP_ZOO_POM));
+    ST_KC(dustToSed, o.sedDust); ST_KC(pfeToSed, o.sedFe);
+    const double DENITRIF = cur.d0 + den_p;
+    ST_KC(DENITRIF, DENITRIF); ST_KC(O2_CONSUMPTION, cur.oc0 + oc_p);
+    ST_KC(Fe_scavenge, Fe_scavenge); ST_KC(Fe_scavenge_rate, o.Fe_scav_rate);
+    jt.C = t_dic + cur.jc;
+    double w1 = t_no3 + t_nh4 + t_donr + cur.jn;
+    jt.N = w1 + DENITRIF + SED_DENITRIF;
+    jt.P = t_po4 + t_dopr + cur.jp;
+    jt.Si = t_sio3 + cur.jsi;
+  }
+  return jt;
+#undef TEND
+#undef ST_KC
+}
+
+// conservation integrals (1870-1938), top to bottom; J[0..7] = C, C 100 m, N, N 100 m, P, P 100 m, Si, Si 100 m
+__device__ __forceinline__ void accumulate_J(double (&J)[8], const JTerms& jt, double dz, double zb, double zbot_above, double sedPOC,
+                                             double sedCa, double sedSi) {
+  const double w2 = dmin(100.0e2 - zbot_above, dz);
+  const double pt100 = (w2 > 0.0) ? w2 : 0.0;
+  const bool shallow = zb <= 100.0e2;
+  J[0] = J[0] + jt.C * dz + sedPOC + sedCa;
+  J[1] = J[1] + jt.C * pt100 + (shallow ? sedPOC + sedCa : 0.0);
+  J[2] = J[2] + jt.N * dz + sedPOC * QN;
+  J[3] = J[3] + jt.N * pt100 + (shallow ? sedPOC * QN : 0.0);
+  J[4] = J[4] + jt.P * dz + sedPOC * QP_ZOO_POM;
+  J[5] = J[5] + jt.P * pt100 + (shallow ? sedPOC * QP_ZOO_POM : 0.0);
+  J[6] = J[6] + jt.Si * dz + sedSi;
+  J[7] = J[7] + jt.Si * pt100 + (shallow ? sedSi : 0.0);
+}
+
 // LANES = active lanes per wavefront (experiment knob, see launch_bgc_ecosys_sweep; 64 is the default).
 template <bool DIAG, int LANES>
 __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
@@ -792,204 +1188,204 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
   const int c = blockIdx.x * LANES + threadIdx.x;
   if (c >= g.ncol) return;
   const obgc_bgc_diag& D = A.diag;
-  const long long pl = g.plane;
   int kmax = A.kmax[c];
   if (kmax > g.nlev) kmax = g.nlev;
-
-#define TEND(slot, ix) A.tend[(long long)((slot)-1) * pl + (ix)]
-#define ST_KC(name, v) do { if (DIAG && D.name) D.name[ix] = (v); } while (0)
 #define ST_C(name, v) do { if (DIAG && D.name) D.name[c] = (v); } while (0)
-
-  // ---- per-column initialisation (BGC_mod.F90:808-811, 2075-2104) ----
-  const double dust_in = (kmax >= 1) ? dmax(0.0, A.dust[c]) : 0.0;
-  Flux fPOC{0.0, 0.0}, fCa{0.0, 0.0}, fSi{0.0, 0.0}, fFe{0.0, 0.0}, fDust{0.0, 0.0};
-  if (dust_in != 0.0) { fDust.s = (1.0 - DUST_GAMMA) * dust_in; fDust.h = DUST_GAMMA * dust_in; }
-  double QA_dust_def = DUST_RHO * (fDust.s + fDust.h);
-  double J_C = 0, J_C100 = 0, J_N = 0, J_N100 = 0, J_P = 0, J_P100 = 0, J_Si = 0, J_Si100 = 0;
-  double zbot_above = 0.0;
+  SweepState S;
+  sweep_init(S, A.dust[c], kmax >= 1);
 
   LevelIn<DIAG> cur, nxt;
   if (kmax >= 1) { load_level<DIAG>(A, P, g.at(0, c), cur); settle<DIAG>(cur); }
   for (int k = 0; k < kmax; ++k) {
     const long long ix = g.at(k, c);
     if (k + 1 < kmax) load_level<DIAG>(A, P, g.at(k + 1, c), nxt);   // in flight while this level is evaluated
-    const double dz = cur.dz, zb = cur.zb, NO3 = dmax(0.0, cur.NO3), Fe = dmax(0.0, cur.Fe), O2 = dmax(0.0, cur.O2);
-    const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
-
-    // dissolution length scales and decay factors across this level (2273-2339): functions of the inputs
-    // this kernel reads anyway, so they are evaluated here instead of travelling through HBM
-    double scalelength;
-    {
-      const double* sz = P.parm_scalelen_z;
-      const double* sv = P.parm_scalelen_vals;
-      if (zb < sz[0]) scalelength = sv[0];
-      else if (zb >= sz[3]) scalelength = sv[3];
-      else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
-      else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
-      else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
-    }
+    // length scales and decay factors are functions of inputs this kernel reads anyway, so they are evaluated here
+    // instead of travelling through HBM
     const double TfuncS = exp((((cur.T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC)) / 10.0) * LN_Q_10);   // 1.5 ** (...)
-    double poc_diss = P.parm_POC_diss;
-    if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
-    else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
-    poc_diss = scalelength * poc_diss;
-    double sio2_diss = scalelength * P.parm_SiO2_diss;
-    const double caco3_diss = scalelength * P.parm_CaCO3_diss;
-    const double dust_diss = scalelength * DUST_DISS;
-    sio2_diss = sio2_diss / TfuncS;
-    const double decay_POC_E = exp(-dz / poc_diss), decay_SiO2 = exp(-dz / sio2_diss), decay_CaCO3 = exp(-dz / caco3_diss),
-                 decay_dust = exp(-dz / dust_diss), DECAY_Hard = exp(-dz / 4.0e6), DECAY_HardDust = exp(-dz / 1.2e7);
-
-    // iron scavenging onto the particles LEAVING the level above (1510-1529)
-    double Fe_scav_rate = P.parm_fe_scavenge_rate0;
-    Fe_scav_rate = Fe_scav_rate * ((fPOC.s + fPOC.h) * 120.1 + (fCa.s + fCa.h) * CACO3_MASS + (fSi.s + fSi.h) * SIO2_MASS +
-                                   (fDust.s + fDust.h) * DUST_FESCAV_SCALE);
-    if (Fe > FE_SCAV_THRES1) Fe_scav_rate = Fe_scav_rate + (Fe - FE_SCAV_THRES1) * FE_MAX_SCALE2;
-    const double Fe_scavenge = YPS * Fe * Fe_scav_rate;
-    const double prodFe = cur.PfeLoc + Fe_scavenge;
-
-    // one step of the Armstrong et al. ballast recurrence (2242-2501)
-    const Flux inPOC = fPOC, inCa = fCa, inSi = fSi, inFe = fFe, inDust = fDust;
-    double sedPOC = 0.0, sedCa = 0.0, sedSi = 0.0, sedDust = 0.0, sedFe = 0.0, SED_DENITRIF = 0.0, OTHER_REMIN = 0.0;
-    const double dzr = 1.0 / dz;
-    fCa.s = inCa.s * decay_CaCO3 + prodCa * ((1.0 - CACO3_GAMMA) * (1.0 - decay_CaCO3) * caco3_diss);
-    fCa.h = inCa.h * DECAY_Hard + prodCa * (CACO3_GAMMA * dz);
-    fSi.s = inSi.s * decay_SiO2 + prodSi * ((1.0 - SIO2_GAMMA) * (1.0 - decay_SiO2) * sio2_diss);
-    fSi.h = inSi.h * DECAY_Hard + prodSi * (SIO2_GAMMA * dz);
-    fDust.s = inDust.s * decay_dust;
-    fDust.h = inDust.h * DECAY_HardDust;
-    double POC_PROD_avail = prodPOC - CACO3_RHO * prodCa - SIO2_RHO * prodSi;
-    double new_def = (QA_dust_def > 0) ? QA_dust_def * (fDust.s + fDust.h) / (inDust.s + inDust.h) : 0.0;
-    if (new_def > 0.0) {
-      new_def = new_def - POC_PROD_avail * dz;
-      if (new_def < 0.0) { POC_PROD_avail = -new_def * dzr; new_def = 0.0; }
-      else POC_PROD_avail = 0.0;
-    }
-    QA_dust_def = new_def;
-    if (inPOC.h == 0.0 && prodPOC == 0.0) {
-      fPOC.h = 0.0;
-    } else {
-      fPOC.h = CACO3_RHO * (fCa.s + fCa.h) + SIO2_RHO * (fSi.s + fSi.h) + DUST_RHO * (fDust.s + fDust.h) - new_def;
-      fPOC.h = dmax(fPOC.h, 0.0);
-    }
-    fPOC.s = inPOC.s * decay_POC_E + POC_PROD_avail * ((1.0 - decay_POC_E) * poc_diss);
-    double reminCa = prodCa + ((inCa.s - fCa.s) + (inCa.h - fCa.h)) * dzr;
-    double reminSi = prodSi + ((inSi.s - fSi.s) + (inSi.h - fSi.h)) * dzr;
-    double reminPOC = prodPOC + ((inPOC.s - fPOC.s) + (inPOC.h - fPOC.h)) * dzr;
-    const double reminDust = ((inDust.s - fDust.s) + (inDust.h - fDust.h)) * dzr;
-    double reminFe;
-    if (inPOC.s + inPOC.h == 0.0) reminFe = (reminPOC * RED_FE_C);
-    else reminFe = (reminPOC * (inFe.s + inFe.h) / (inPOC.s + inPOC.h));
-    reminFe = reminFe + (inFe.s * 1.5e-5);
-    fFe.s = inFe.s + dz * ((1.0 - 0.0) * prodFe - reminFe);
-    if (fFe.s < 0.0) {
-      fFe.s = 0.0;
-      reminFe = inFe.s * dzr + (1.0 - 0.0) * prodFe;
-    }
-    reminFe = reminFe + reminDust * DUST_TO_FE + (cur.fesed * dzr);
-    fFe.h = inFe.h;
-
-    if (k == kmax - 1) {   // sea floor: burial, sediment denitrification, instantaneous remin (2522-2631)
-      double flux = fPOC.s + fPOC.h, flux_alt;
-      if (flux > 0.0) {
-        flux_alt = flux * 0.01 * SPD;
-        sedPOC = flux * dmin(0.8, P.parm_POMbury * (0.013 + 0.53 * flux_alt * flux_alt / ((7.0 + flux_alt) * (7.0 + flux_alt))));
-        SED_DENITRIF = dzr * flux * (0.06 + 0.19 * exp((O2 - NO3) * LN_0_99));   // 0.99 ** (O2 - NO3)
-        if (NO3 < 5.0) SED_DENITRIF = 0.0;
-        flux_alt = flux * 1.0e-6 * SPD * 365.0;
-        OTHER_REMIN = dzr * dmin(dmin(0.1 + flux_alt, 0.5) * (flux - sedPOC), (flux - sedPOC - (SED_DENITRIF * dz * DENITRIF_C_N)));
-        if (O2 < 1.0) OTHER_REMIN = dzr * (flux - sedPOC - (SED_DENITRIF * dz * DENITRIF_C_N));
-      }
-      flux = fSi.s + fSi.h;
-      flux_alt = flux * 0.01 * SPD;
-      sedSi = (flux_alt > 2.0) ? 0.2 : 0.04;
-      sedSi = flux * P.parm_BSIbury * sedSi;
-      if (zb < 3300.0e2) sedCa = fCa.s + fCa.h;
-      flux = fCa.s + fCa.h;
-      if (flux > 0.0) reminCa = reminCa + ((flux - sedCa) * dzr);
-      flux = fSi.s + fSi.h;
-      if (flux > 0.0) reminSi = reminSi + ((flux - sedSi) * dzr);
-      flux = fPOC.s + fPOC.h;
-      if (flux > 0.0) reminPOC = reminPOC + ((flux - sedPOC) * dzr);
-      flux = (fFe.s + fFe.h);
-      if (flux > 0.0) sedFe = flux;
-      sedDust = fDust.s + fDust.h;
-      fCa = Flux{0.0, 0.0}; fSi = Flux{0.0, 0.0}; fDust = Flux{0.0, 0.0}; fPOC = Flux{0.0, 0.0}; fFe = Flux{0.0, 0.0};
-    }
-
-    // ---- denitrification (1569-1577) and the particle-dependent tendencies (1583-1790): the cell kernel
-    //      left every local term in the tendency planes; only the remineralisation terms are added here ----
-    double wd = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
-    wd = dmin(dmax(wd, 0.0), 1.0);
-    if (NO3 == 0.0) wd = 0.0;
-    const double den_p = wd * ((reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
-    const double t_no3 = (cur.L_no3 - den_p) - SED_DENITRIF;
-    const double t_nh4 = cur.L_nh4 + QN * (reminPOC * (1.0 - DONREFRACT));
-    const double t_fe = (reminFe + cur.L_fe) - Fe_scavenge;
-    const double t_sio3 = reminSi + cur.L_sio3;
-    const double t_po4 = cur.L_po4 + QP_ZOO_POM * ((1.0 - DOPREFRACT) * reminPOC);
-    const double t_donr = cur.L_donr + (reminPOC * DONREFRACT * QN);
-    const double t_dopr = cur.L_dopr + (reminPOC * DOPREFRACT * QP_ZOO_POM);
-    const double t_dic = (cur.L_dic + reminPOC) + reminCa;
-    const double t_alk = (-t_no3 + t_nh4 + 2.0 * reminCa) + cur.L_alk;
-    double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
-    wo = dmin(dmax(wo, 0.0), 1.0);
-    const double oc_p = wo * ((reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN) / REMIN_D_C_O2);
-    double w1;
-    TEND(P.ind[1], ix) = t_no3;
-    TEND(P.ind[3], ix) = t_nh4;
-    TEND(P.ind[4], ix) = t_fe;
-    TEND(P.ind[2], ix) = t_sio3;
-    TEND(P.ind[0], ix) = t_po4;
-    TEND(P.ind[14], ix) = t_donr;
-    TEND(P.ind[13], ix) = t_dopr;
-    TEND(P.ind[6], ix) = t_dic;
-    TEND(P.ind[7], ix) = A.alt_co2_use_eco ? t_dic : 0.0;
-    TEND(P.ind[8], ix) = t_alk;
-    TEND(P.ind[5], ix) = cur.L_o2 - oc_p;
-
-    if (DIAG) {   // 2637-2694, 1563-1577, 1866-1868
-      ST_KC(POC_FLUX_IN, inPOC.s + inPOC.h); ST_KC(POC_PROD, prodPOC); ST_KC(POC_REMIN, reminPOC);
-      ST_KC(CaCO3_FLUX_IN, inCa.s + inCa.h); ST_KC(CaCO3_PROD, prodCa); ST_KC(CaCO3_REMIN, reminCa);
-      ST_KC(SiO2_FLUX_IN, inSi.s + inSi.h); ST_KC(SiO2_PROD, prodSi); ST_KC(SiO2_REMIN, reminSi);
-      ST_KC(dust_FLUX_IN, inDust.s + inDust.h); ST_KC(dust_REMIN, reminDust);
-      ST_KC(P_iron_FLUX_IN, inFe.s + inFe.h); ST_KC(P_iron_PROD, prodFe); ST_KC(P_iron_REMIN, reminFe);
-      ST_KC(calcToSed, sedCa); ST_KC(bsiToSed, sedSi); ST_KC(pocToSed, sedPOC);
-      ST_KC(SedDenitrif, SED_DENITRIF * dz); ST_KC(OtherRemin, OTHER_REMIN * dz);
-      ST_KC(ponToSed, (sedPOC * QN)); ST_KC(popToSed, (sedPOC * QP_ZOO_POM));
-      ST_KC(dustToSed, sedDust); ST_KC(pfeToSed, sedFe);
-      const double DENITRIF = cur.d0 + den_p;
-      ST_KC(DENITRIF, DENITRIF); ST_KC(O2_CONSUMPTION, cur.oc0 + oc_p);
-      ST_KC(Fe_scavenge, Fe_scavenge); ST_KC(Fe_scavenge_rate, Fe_scav_rate);
-      // conservation integrals (1870-1938): local parts from the cell kernel + the tendencies finished here
-      const double w2 = dmin(100.0e2 - zbot_above, dz);
-      const double pt100 = (w2 > 0.0) ? w2 : 0.0;
-      const bool shallow = zb <= 100.0e2;
-      w1 = t_dic + cur.jc;
-      J_C = J_C + w1 * dz + sedPOC + sedCa;
-      J_C100 = J_C100 + w1 * pt100 + (shallow ? sedPOC + sedCa : 0.0);
-      w1 = t_no3 + t_nh4 + t_donr + cur.jn;
-      w1 = w1 + DENITRIF + SED_DENITRIF;
-      J_N = J_N + w1 * dz + sedPOC * QN;
-      J_N100 = J_N100 + w1 * pt100 + (shallow ? sedPOC * QN : 0.0);
-      w1 = t_po4 + t_dopr + cur.jp;
-      J_P = J_P + w1 * dz + sedPOC * QP_ZOO_POM;
-      J_P100 = J_P100 + w1 * pt100 + (shallow ? sedPOC * QP_ZOO_POM : 0.0);
-      w1 = t_sio3 + cur.jsi;
-      J_Si = J_Si + w1 * dz + sedSi;
-      J_Si100 = J_Si100 + w1 * pt100 + (shallow ? sedSi : 0.0);
-    }
-    zbot_above = zb;
+    const LevelDerived dv = derive_level(P, cur.zb, TfuncS, dmax(0.0, cur.O2), cur.dz);
+    SweepCoreOut o;
+    sweep_core(P, k == kmax - 1, cur.dz, cur.zb, cur.fesed, dmax(0.0, cur.NO3), dmax(0.0, cur.Fe), dmax(0.0, cur.O2), cur.prodPOC,
+               cur.prodCa, cur.prodSi, cur.PfeLoc, dv, S, o);
+    const JTerms jt = sweep_finish<DIAG>(A, P, ix, cur, o);
+    if (DIAG) accumulate_J(S.J, jt, cur.dz, cur.zb, S.zbot_above, o.sedPOC, o.sedCa, o.sedSi);
+    S.zbot_above = cur.zb;
     cur = nxt;
   }   // k
 
   if (DIAG) {
-    ST_C(Jint_Ctot, J_C); ST_C(Jint_100m_Ctot, J_C100); ST_C(Jint_Ntot, J_N); ST_C(Jint_100m_Ntot, J_N100);
-    ST_C(Jint_Ptot, J_P); ST_C(Jint_100m_Ptot, J_P100); ST_C(Jint_Sitot, J_Si); ST_C(Jint_100m_Sitot, J_Si100);
+    ST_C(Jint_Ctot, S.J[0]); ST_C(Jint_100m_Ctot, S.J[1]); ST_C(Jint_Ntot, S.J[2]); ST_C(Jint_100m_Ntot, S.J[3]);
+    ST_C(Jint_Ptot, S.J[4]); ST_C(Jint_100m_Ptot, S.J[5]); ST_C(Jint_Sitot, S.J[6]); ST_C(Jint_100m_Sitot, S.J[7]);
   }
-#undef TEND
-#undef ST_KC
 #undef ST_C
+}
+
+// the recurrence state of a column (five fluxes, the dust deficit) to / from its LDS row
+constexpr int kStateVals = 11;
+__device__ __forceinline__ void state_store(const SweepState& S, double (*st)[64], int lane) {
+  st[0][lane] = S.fPOC.s; st[1][lane] = S.fPOC.h; st[2][lane] = S.fCa.s; st[3][lane] = S.fCa.h; st[4][lane] = S.fSi.s;
+  st[5][lane] = S.fSi.h; st[6][lane] = S.fFe.s; st[7][lane] = S.fFe.h; st[8][lane] = S.fDust.s; st[9][lane] = S.fDust.h;
+  st[10][lane] = S.QA_dust_def;
+}
+__device__ __forceinline__ void state_load(SweepState& S, double (*st)[64], int lane) {
+  S.fPOC.s = st[0][lane]; S.fPOC.h = st[1][lane]; S.fCa.s = st[2][lane]; S.fCa.h = st[3][lane]; S.fSi.s = st[4][lane];
+  S.fSi.h = st[5][lane]; S.fFe.s = st[6][lane]; S.fFe.h = st[7][lane]; S.fDust.s = st[8][lane]; S.fDust.h = st[9][lane];
+  S.QA_dust_def = st[10][lane];
+  S.zbot_above = 0.0;
+}
+
+// ------------------------------------------------------------------------- column-block kernel
+// The whole ecosystem part of BGC_SourceSink (and, for obgc_fused_step, DMS_SourceSink and MACROS_SourceSink) in ONE
+// launch for callers in the native layout.  A workgroup owns 64 adjacent columns and marches down them in chunks of
+// kColLevels levels; wavefront w evaluates the cell terms of level 4 j + w (lane = column, every load and store a
+// contiguous 512-byte row).  What the separate kernels pass through HBM stays on the chip:
+//   * light: each wavefront computes its level's attenuation; the product down the chunk runs through 2 KB of LDS and
+//     the PAR entering the next chunk is carried in LDS (no attenuation / scan kernels, no light planes);
+//   * particles: the cell terms leave the inputs of the recurrence (production terms, length scales, decay factors: 19
+//     values) in LDS; one wavefront runs the ~100 sequential flops per level of the ballast recurrence over the chunk's
+//     levels (state of the 64 columns in LDS between chunks) and leaves its results in the same slots; every lane then
+//     finishes its own cell: the particle-dependent part of 11 tendencies and 27 diagnostics (no hand-off planes, no
+//     tendency written twice, no second read of dz, zbot, T, O2, NO3, Fe by a sweep kernel).
+// Three barriers per chunk: attenuations in LDS, recurrence inputs in LDS, recurrence results in LDS.  Same statements in
+// the same order as the separate kernels, hence the same bits (tests/test_gpu_column_kernel.py).  The conservation
+// integrals are the exception in form only: their integrands go to four scratch planes and the column-integral kernel
+// sums them top to bottom, in the sweep kernel's order.
+// FUSE = 1: every lane goes on to solve the carbonate system of its cell (obgc_co2.h), as bgc_cell_kernel<.., 1> does.
+#ifdef OBGC_COLTIMING
+// Development build only (make BUILD=build_timing CXXEXTRA=-DOBGC_COLTIMING): shader-clock cycles per phase of the chunk
+// loop, summed over the wavefronts of a launch by wavefront index; printed by launch_bgc_column.
+__device__ unsigned long long g_coltiming[8][kColLevels];
+#define OBGC_T(i) do { __builtin_amdgcn_s_waitcnt(0xc07f | 0); tnow = __builtin_readcyclecounter(); tacc[i] += tnow - tlast; tlast = tnow; } while (0)
+#else
+#define OBGC_T(i) do { } while (0)
+#endif
+
+template <bool DIAG, bool DM, int FUSE>
+__global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKernelArgs A, const obgc_bgc_params P, const FusedDmArgs F,
+                                                                    const FusedParams FP) {
+  __shared__ double s_ho[H_NSLOTS][kColThreads];
+  __shared__ double s_att[kColLevels][64], s_par[2][64];
+  __shared__ double s_attd[DM ? kColLevels : 1][64], s_pard[DM ? 2 : 1][64];
+  // The recurrence state of the 64 columns rests in LDS between chunks: whichever wavefront walks a chunk holds it in
+  // registers only while it does, so the cell terms do not share the register file with it.
+  __shared__ double s_state[kStateVals][64];
+  const GridView& g = A.g;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool colvalid = c < g.ncol;
+  const int cc = colvalid ? c : g.ncol - 1;
+  int kmax = A.kmax[cc];
+  if (kmax > g.nlev) kmax = g.nlev;
+  if (!colvalid) kmax = 0;
+  if (w == 0) {   // read behind the first barrier
+    SweepState S;
+    sweep_init(S, A.dust[cc], kmax >= 1);
+    state_store(S, s_state, lane);
+    const double sw = dmax(0.0, A.sw[cc]);   // PAR entering the first level (BGC_mod.F90:813-814; DMS_mod.F90:506-507)
+    s_par[0][lane] = sw * F_QSW_PAR;
+    if (DM) s_pard[0][lane] = sw * F.f_qsw_par_dms;
+  }
+  const int nchunk = (g.nlev + kColLevels - 1) / kColLevels;
+#ifdef OBGC_COLTIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tnow, tlast = __builtin_readcyclecounter();
+#endif
+  for (int j = 0; j < nchunk; ++j) {
+    ColCtx X;
+    X.k = j * kColLevels + w; X.c = c; X.w = w; X.lane = lane;
+    X.valid = colvalid && X.k < g.nlev;
+    X.parity = j & 1;
+    X.ho = &s_ho[0][0]; X.att = &s_att[0][0]; X.par = &s_par[0][0]; X.attd = &s_attd[0][0]; X.pard = &s_pard[0][0];
+    // The kernel arguments are read through pointers the optimiser must take as new in every chunk: otherwise it hoists
+    // the ~250 scalar loads of array pointers and parameters out of the loop and then spills them (1 600 SGPRs into 26
+    // VGPRs) -- inside one chunk they are loaded where they are used, as in the kernels without a loop.
+    // (An offset of zero the optimiser cannot see through keeps the pointers in the kernel-argument address space.)
+    long long zero = 0;
+    asm volatile("" : "+s"(zero));
+    const BgcKernelArgs* Ap = (const BgcKernelArgs*)((const char*)&A + zero);
+    const obgc_bgc_params* Pp = (const obgc_bgc_params*)((const char*)&P + zero);
+    const FusedDmArgs* Fp = (const FusedDmArgs*)((const char*)&F + zero);
+    const FusedParams* FPp = (const FusedParams*)((const char*)&FP + zero);
+    LevelIn<DIAG> lo;
+    const int kc = X.k < g.nlev ? X.k : g.nlev - 1;      // invalid lanes work on clamped addresses and store nothing
+    CellIn in;
+    cell_load<DIAG, DM, true>(*Ap, *Pp, DM ? Fp : nullptr, kc, cc, in);
+#ifdef OBGC_COLTIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OBGC_T(0);   // the chunk's loads (behind the stores of the chunk before)
+#endif
+    const bool active = cell_body<DIAG, DM, true>(*Ap, *Pp, DM ? Fp : nullptr, DM ? FPp : nullptr, &X, &lo, kc, cc, in);
+    OBGC_T(1);   // cell terms (with the light barrier inside)
+    lds_barrier();   // the chunk's recurrence inputs are in LDS
+    OBGC_T(2);
+    // One wavefront walks the chunk's levels for the 64 columns -- a different one in every chunk, so that the four SIMDs
+    // share the walk -- reading a cell's inputs from LDS and leaving its results in the same slots.
+    if (w == (j & (kColLevels - 1)) && j * kColLevels < kmax) {
+      SweepState S;
+      state_load(S, s_state, lane);
+#pragma unroll 1
+      for (int l = 0; l < kColLevels; ++l) {
+        const int k = j * kColLevels + l;
+        if (k < kmax) {
+          const int t = l * 64 + lane;
+          LevelDerived dv;
+          dv.poc_diss = s_ho[H_POC_DISS][t]; dv.sio2_diss = s_ho[H_SIO2_DISS][t]; dv.caco3_diss = s_ho[H_CACO3_DISS][t];
+          dv.decay_POC_E = s_ho[H_DEC_POC][t]; dv.decay_SiO2 = s_ho[H_DEC_SI][t]; dv.decay_CaCO3 = s_ho[H_DEC_CA][t];
+          dv.decay_dust = s_ho[H_DEC_DUST][t]; dv.DECAY_Hard = s_ho[H_DEC_HARD][t]; dv.DECAY_HardDust = s_ho[H_DEC_HARDDUST][t];
+          SweepCoreOut o;
+          sweep_core(*Pp, k == kmax - 1, s_ho[H_DZ][t], s_ho[H_ZB][t], s_ho[H_FESED][t], s_ho[H_NO3][t], s_ho[H_FE][t], s_ho[H_O2][t],
+                     s_ho[H_PRODPOC][t], s_ho[H_PRODCA][t], s_ho[H_PRODSI][t], s_ho[H_PFELOC][t], dv, S, o);
+          s_ho[H_OUT_REMINPOC][t] = o.reminPOC; s_ho[H_OUT_REMINCA][t] = o.reminCa; s_ho[H_OUT_REMINSI][t] = o.reminSi;
+          s_ho[H_OUT_REMINFE][t] = o.reminFe; s_ho[H_OUT_FESCAV][t] = o.Fe_scavenge; s_ho[H_OUT_SEDDEN][t] = o.SED_DENITRIF;
+          s_ho[H_OUT_OTHER][t] = o.OTHER_REMIN;
+          if (DIAG) {
+            s_ho[H_OUT_INPOC][t] = o.inPOC; s_ho[H_OUT_INCA][t] = o.inCa; s_ho[H_OUT_INSI][t] = o.inSi; s_ho[H_OUT_INDUST][t] = o.inDust;
+            s_ho[H_OUT_INFE][t] = o.inFe; s_ho[H_OUT_REMINDUST][t] = o.reminDust; s_ho[H_OUT_FESCAVRATE][t] = o.Fe_scav_rate;
+            s_ho[H_OUT_SEDPOC][t] = o.sedPOC; s_ho[H_OUT_SEDCA][t] = o.sedCa; s_ho[H_OUT_SEDSI][t] = o.sedSi;
+            s_ho[H_OUT_SEDDUST][t] = o.sedDust; s_ho[H_OUT_SEDFE][t] = o.sedFe;
+          }
+        }
+      }
+      state_store(S, s_state, lane);
+    }
+    OBGC_T(3);   // the walk (one wavefront per chunk)
+    lds_barrier();   // the recurrence has passed the chunk
+    OBGC_T(4);
+    if (active) {
+      const int t = threadIdx.x;
+      const long long ix = g.at(X.k, c);
+      SweepCoreOut o;
+      o.reminPOC = s_ho[H_OUT_REMINPOC][t]; o.reminCa = s_ho[H_OUT_REMINCA][t]; o.reminSi = s_ho[H_OUT_REMINSI][t];
+      o.reminFe = s_ho[H_OUT_REMINFE][t]; o.Fe_scavenge = s_ho[H_OUT_FESCAV][t]; o.SED_DENITRIF = s_ho[H_OUT_SEDDEN][t];
+      o.OTHER_REMIN = s_ho[H_OUT_OTHER][t];
+      if (DIAG) {
+        o.inPOC = s_ho[H_OUT_INPOC][t]; o.inCa = s_ho[H_OUT_INCA][t]; o.inSi = s_ho[H_OUT_INSI][t]; o.inDust = s_ho[H_OUT_INDUST][t];
+        o.inFe = s_ho[H_OUT_INFE][t]; o.reminDust = s_ho[H_OUT_REMINDUST][t]; o.Fe_scav_rate = s_ho[H_OUT_FESCAVRATE][t];
+        o.sedPOC = s_ho[H_OUT_SEDPOC][t]; o.sedCa = s_ho[H_OUT_SEDCA][t]; o.sedSi = s_ho[H_OUT_SEDSI][t];
+        o.sedDust = s_ho[H_OUT_SEDDUST][t]; o.sedFe = s_ho[H_OUT_SEDFE][t];
+      }
+      lo.L_no3 = s_ho[H_L_NO3][t]; lo.L_nh4 = s_ho[H_L_NH4][t]; lo.L_fe = s_ho[H_L_FE][t]; lo.L_sio3 = s_ho[H_L_SIO3][t];
+      lo.L_po4 = s_ho[H_L_PO4][t]; lo.L_donr = s_ho[H_L_DONR][t]; lo.L_dopr = s_ho[H_L_DOPR][t]; lo.L_dic = s_ho[H_L_DIC][t];
+      lo.L_alk = s_ho[H_L_ALK][t]; lo.L_o2 = s_ho[H_L_O2][t];
+      const JTerms jt = sweep_finish<DIAG>(*Ap, *Pp, ix, lo, o);
+      if (DIAG) {
+        // integrands of the conservation integrals: summed top to bottom by the column-integral kernel
+        double* jw = Ap->jw;
+        const long long sp = Ap->splane;
+        jw[ix] = jt.C; jw[sp + ix] = jt.N; jw[2 * sp + ix] = jt.P; jw[3 * sp + ix] = jt.Si;
+        if (X.k == kmax - 1) {
+          double* js = Ap->jsed;
+          js[c] = o.sedPOC; js[g.ncol + c] = o.sedCa; js[2LL * g.ncol + c] = o.sedSi;
+        }
+      }
+    }
+    OBGC_T(5);   // finish
+    // no barrier here: the next chunk's first write into the slots sits behind its light barrier
+    if (FUSE) carbonate_cell(*Ap, Pp->ind[6], Pp->ind[8], Pp->ind[0], Pp->ind[2], X.valid, X.k, X.valid ? c : 0);
+    OBGC_T(6);
+  }
+#ifdef OBGC_COLTIMING
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_coltiming[i][w], tacc[i]);
+#endif
 }
 
 // ---------------------------------------------------------------- column integrals (diagnostics only)
@@ -1008,7 +1404,11 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
   double z_bSi = 0.0, z_CaTot = 0.0, z_pCTot = 0.0, z_pCNO3Tot = 0.0, z_Chl100 = 0.0;
   double z_Ca[4] = {0, 0, 0, 0}, z_pC[4] = {0, 0, 0, 0}, z_pCNO3[4] = {0, 0, 0, 0};
   double o2min = 0.0, o2min_z = 0.0;
-  const double* chl100 = A.scratch + (long long)S_CHL100 * A.splane;
+  const double* chl100 = A.chl100;
+  // column-block kernel only: the conservation integrals from the integrands its cells left (jw), in the sweep's order
+  const bool do_j = A.jw != nullptr;
+  double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double zbot_above = 0.0;
   const double* o2p = A.tracers + (long long)(P.ind[5] - 1) * pl;
 #pragma unroll 2
   for (int k = 0; k < kmax; ++k) {
@@ -1035,6 +1435,24 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
       z_pCNO3Tot = z_pCNO3Tot + z_pCNO3[a];   // adds the RUNNING integral (1844-1846)
     }
     z_Chl100 = z_Chl100 + chl100[ix];
+    if (do_j) {
+      const JTerms jt{A.jw[ix], A.jw[A.splane + ix], A.jw[2 * A.splane + ix], A.jw[3 * A.splane + ix]};
+      const double zb = A.zbot[ix];
+      const bool bottom = k == kmax - 1;
+      accumulate_J(J, jt, dz, zb, zbot_above, bottom ? A.jsed[c] : 0.0, bottom ? A.jsed[g.ncol + c] : 0.0,
+                   bottom ? A.jsed[2LL * g.ncol + c] : 0.0);
+      zbot_above = zb;
+    }
+  }
+  if (do_j) {
+    if (D.Jint_Ctot) D.Jint_Ctot[c] = J[0];
+    if (D.Jint_100m_Ctot) D.Jint_100m_Ctot[c] = J[1];
+    if (D.Jint_Ntot) D.Jint_Ntot[c] = J[2];
+    if (D.Jint_100m_Ntot) D.Jint_100m_Ntot[c] = J[3];
+    if (D.Jint_Ptot) D.Jint_Ptot[c] = J[4];
+    if (D.Jint_100m_Ptot) D.Jint_100m_Ptot[c] = J[5];
+    if (D.Jint_Sitot) D.Jint_Sitot[c] = J[6];
+    if (D.Jint_100m_Sitot) D.Jint_100m_Sitot[c] = J[7];
   }
   if (D.O2_ZMIN) D.O2_ZMIN[c] = o2min;
   if (D.O2_ZMIN_DEPTH) D.O2_ZMIN_DEPTH[c] = o2min_z;
@@ -1103,6 +1521,44 @@ void launch_fused_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p,
     else hipLaunchKernelGGL((fused_cell_kernel<false, 0>), dim3(gcell), dim3(kBlockCell), 0, s, a, p, f, fp);
   }
   if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
+}
+
+void launch_bgc_column(const BgcKernelArgs& a, const obgc_bgc_params& p, const FusedDmArgs* f, const FusedParams* fp, hipStream_t s,
+                       int fuse_carbonate) {
+  if (a.g.ncol <= 0) return;
+  const unsigned grid = (unsigned)((a.g.ncol + 63) / 64);
+  FusedDmArgs f0;
+  FusedParams fp0;
+  if (!f) { std::memset(&f0, 0, sizeof f0); std::memset(&fp0, 0, sizeof fp0); }
+  const FusedDmArgs& F = f ? *f : f0;
+  const FusedParams& FP = fp ? *fp : fp0;
+#define OBGC_LAUNCH_COL(DIAG, DM, FUSE) hipLaunchKernelGGL((bgc_column_kernel<DIAG, DM, FUSE>), dim3(grid), dim3(kColThreads), 0, s, a, p, F, FP)
+  const bool dm = f != nullptr;
+  if (a.have_diag) {
+    if (dm) { if (fuse_carbonate) OBGC_LAUNCH_COL(true, true, 1); else OBGC_LAUNCH_COL(true, true, 0); }
+    else { if (fuse_carbonate) OBGC_LAUNCH_COL(true, false, 1); else OBGC_LAUNCH_COL(true, false, 0); }
+  } else {
+    if (dm) { if (fuse_carbonate) OBGC_LAUNCH_COL(false, true, 1); else OBGC_LAUNCH_COL(false, true, 0); }
+    else { if (fuse_carbonate) OBGC_LAUNCH_COL(false, false, 1); else OBGC_LAUNCH_COL(false, false, 0); }
+  }
+#undef OBGC_LAUNCH_COL
+#ifdef OBGC_COLTIMING
+  {
+    (void)hipDeviceSynchronize();
+    unsigned long long t[8][kColLevels];
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_coltiming), sizeof t);
+    const char* nm[8] = {"loads", "cell terms", "barrier 1", "walk", "barrier 2", "finish", "carbonate", "-"};
+    const double nwg = (double)grid, nch = (double)((a.g.nlev + kColLevels - 1) / kColLevels);
+    std::fprintf(stderr, "column kernel: cycles per chunk and wavefront (mean over %u workgroups x %.0f chunks)\n", grid, nch);
+    for (int i = 0; i < 7; ++i) {
+      std::fprintf(stderr, "  %-11s", nm[i]);
+      for (int ww = 0; ww < kColLevels; ++ww) std::fprintf(stderr, " %9.0f", (double)t[i][ww] / (nwg * nch));
+      std::fprintf(stderr, "\n");
+    }
+    std::memset(t, 0, sizeof t);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_coltiming), t, sizeof t);
+  }
+#endif
 }
 
 void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {

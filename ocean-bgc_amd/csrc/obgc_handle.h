@@ -25,6 +25,8 @@ struct obgc_handle {
   int kfast_hybrid = 1;   // OBGC_KFAST_HYBRID=0: transpose every plane (the first implementation) instead of only the column kernels' planes
   int sched = -1;  // OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel, 2 carbonate inside the cell kernel's
                    // wavefronts, -1 (default) = 1, or for batches of more than 10 M cells 2 with diagnostics and 0 without (see bgc_launch)
+  int column = 1;  // OBGC_COLUMN_KERNEL=0: native-layout calls use the separate attenuation / scan / cell / sweep kernels (the form the
+                   // reference layout always takes) instead of the column-block kernel
   obgc_bgc_params bgc;
   obgc_dms_params dms;
   obgc_macros_params macros;

@@ -6,6 +6,10 @@
 
 #include "obgc.h"
 
+// Diagnostic planes are written once and not read again by the kernel that writes them: streamed past the caches
+// (-3.5 % on the column-block kernel at 1 M columns x 80 levels with every diagnostic; the same bits)
+#define OBGC_STORE(p, v) __builtin_nontemporal_store((v), (p))
+
 namespace obgc {
 
 // Strided view of the level-dependent arrays of one call.  Element (k, c) of plane n
@@ -60,6 +64,10 @@ struct BgcKernelArgs {
   // integrates vertically: the caller's diagnostic arrays when given, else scratch (4 planes each)
   double* scratch;
   long long splane;
+  double* chl100;   // diagnostics only: chlorophyll x thickness above 100 m of every cell, summed by the column-integral kernel
+  // column-block kernel with diagnostics: integrands of the four conservation integrals (4 planes, stride splane) and the
+  // three burial fluxes of each column's bottom cell (3 vectors, stride ncol); NULL otherwise (the sweep kernel sums them)
+  double *jw, *jsed;
   double *z_photoC, *z_photoC_NO3, *z_CaCO3_form, *z_bSi_form;
   obgc_bgc_diag diag;
   int have_diag;
@@ -177,6 +185,10 @@ struct FusedParams {
   obgc_dms_params dms;
   obgc_macros_params macros;
 };
+// the column-block kernel: attenuation, scan, cell terms and sweep of the native layout in one launch; f / fp non-NULL adds
+// the DMS / MACROS terms of obgc_fused_step
+void launch_bgc_column(const BgcKernelArgs& a, const obgc_bgc_params& p, const FusedDmArgs* f, const FusedParams* fp, hipStream_t s,
+                       int fuse_carbonate);
 void launch_fused_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, const FusedDmArgs& f, const FusedParams& fp, hipStream_t s,
                                hipEvent_t ev_cell0, hipEvent_t ev_cell1, int fuse_carbonate);
 

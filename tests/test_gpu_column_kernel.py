@@ -1,0 +1,116 @@
+"""The column-block kernel (attenuation, PAR scan, cell terms and particle sweep of the native layout in ONE launch, light
+and hand-off in LDS) against the separate kernels it replaces (OBGC_COLUMN_KERNEL=0, the form the reference layout still
+takes): same statements in the same order, so EVERY output must be bit-identical -- with and without diagnostics, with
+the DMS / MACROS terms of the fused step, with the carbonate solve inside or beside it, for column counts that do not
+fill the last 64-column block and level counts that do not fill the last 4-level chunk."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(monkeypatch, sched=None):
+    from ocean_bgc_amd.modules import ColumnEngine
+    if sched is not None:
+        monkeypatch.setenv("OBGC_SCHED", str(sched))
+    monkeypatch.setenv("OBGC_COLUMN_KERNEL", "0")
+    old = ColumnEngine(0, path="device_colfast")
+    monkeypatch.setenv("OBGC_COLUMN_KERNEL", "1")
+    new = ColumnEngine(0, path="device_colfast")
+    return old, new
+
+
+def _same(a, b, what):
+    for key in ("tend", "ph_prev", "ph_prev_alt"):
+        if key in a:
+            assert np.array_equal(a[key], b[key]), "%s %s" % (what, key)
+    for grp in ("kc", "kca", "ca", "c"):
+        for nm, v in a.get(grp, {}).items():
+            assert np.array_equal(v, b[grp][nm]), "%s %s.%s" % (what, grp, nm)
+
+
+@pytest.mark.parametrize("nc,nz,diag,sched", [(20_000, 60, True, None), (5_003, 80, False, None), (777, 62, True, 0), (4_096, 100, True, 2),
+                                              (130, 61, False, 1), (1, 60, True, None)])
+def test_bgc_source_sink_bit_identical(pkg, synth, monkeypatch, nc, nz, diag, sched):
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    old, new = _engines(monkeypatch, sched)
+    syn = synth.generate(nc, nz, col0=424_242)
+    tr = synth.bgc_tracer_array(syn)
+    args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+            syn["sw"])
+    z = np.zeros((nc, nz))
+    a = old.BGC_SourceSink(*args, z, z, diag_init=-5.0, diagnostics=diag)
+    b = new.BGC_SourceSink(*args, z, z, diag_init=-5.0, diagnostics=diag)
+    assert old.eng.last_schedule() in (0, 1, 2) and new.eng.last_schedule() in (3, 4)
+    _same(a, b, "cold")
+    assert np.isfinite(b["tend"]).all() and (b["tend"] != -5.0).all()
+    a2 = old.BGC_SourceSink(tr * 1.003, *args[1:], a["ph_prev"], a["ph_prev_alt"], alt_co2_use_eco=False, diag_init=-5.0, diagnostics=diag)
+    b2 = new.BGC_SourceSink(tr * 1.003, *args[1:], a["ph_prev"], a["ph_prev_alt"], alt_co2_use_eco=False, diag_init=-5.0, diagnostics=diag)
+    _same(a2, b2, "warm")
+
+
+@pytest.mark.parametrize("nc,nz,diag", [(10_000, 80, True), (3_001, 60, False)])
+def test_fused_step_bit_identical(pkg, synth, monkeypatch, nc, nz, diag):
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    old, new = _engines(monkeypatch)
+    syn = synth.generate(nc, nz, col0=77)
+    t = syn["tracers"]
+    rng = np.random.RandomState(9)
+    t["spFe"] = np.where(rng.rand(nc, nz) < 0.002, 0.0, t["spFe"])      # columns where DMS cannot share BGC's light
+    t["spFe"][5::10, 1] = 0.0
+    tr, dtr, mtr = synth.bgc_tracer_array(syn), synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)
+    args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+            syn["sw"])
+    z = np.zeros((nc, nz))
+    sst = syn["forcing"]["SST"]
+    a = old.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0, diagnostics=diag)
+    b = new.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0, diagnostics=diag)
+    for part in ("bgc", "dms", "macros"):
+        _same(a[part], b[part], part)
+    # and against the stand-alone DMS / MACROS entry points
+    d = new.DMS_SourceSink(dtr, syn["dz"], syn["kmax"], sst, syn["sw"], diag_init=-5.0)
+    m = new.MACROS_SourceSink(mtr, syn["kmax"], diag_init=-5.0)
+    assert np.array_equal(d["tend"], b["dms"]["tend"]) and np.array_equal(m["tend"], b["macros"]["tend"])
+    if diag:
+        _same(d, b["dms"], "dms alone")
+        _same(m, b["macros"], "macros alone")
+
+
+def test_crafted_columns_bit_identical(pkg, synth, monkeypatch):
+    """bracket growth, surviving dust deficit, empty column, iron clamp (tests/crafted.py)"""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    import crafted
+    old, new = _engines(monkeypatch)
+    syn, php = crafted.crafted_columns(synth)
+    args = (synth.bgc_tracer_array(syn), syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
+            syn["fesed"], syn["dust"], syn["sw"])
+    _same(old.BGC_SourceSink(*args, php, php.copy(), diag_init=-5.0), new.BGC_SourceSink(*args, php, php.copy(), diag_init=-5.0), "crafted")
+
+
+@pytest.mark.parametrize("knob", ["default", "OBGC_KFAST_HYBRID=0", "OBGC_KFAST_DIRECT=1"])
+def test_reference_layout_forms_match_native(pkg, synth, monkeypatch, knob):
+    """Every way the reference (level-fastest) layout is served on the device -- cell kernels on the caller's arrays with
+    LDS transposes for the column kernels (default), a whole native workspace per column tile (OBGC_KFAST_HYBRID=0, which
+    runs the column-block kernel on the workspace) and generic strides (OBGC_KFAST_DIRECT=1) -- gives the native layout's
+    bits, over several column tiles with a short last one."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    from ocean_bgc_amd.modules import ColumnEngine
+    nc, nz = 2_500, 61
+    syn = synth.generate(nc, nz, col0=31_337)
+    tr = synth.bgc_tracer_array(syn)
+    args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+            syn["sw"])
+    z = np.zeros((nc, nz))
+    native = ColumnEngine(0, path="device_colfast").BGC_SourceSink(*args, z, z, diag_init=-5.0)
+    monkeypatch.setenv("OBGC_KFAST_TILE", "1024")
+    if knob != "default":
+        k, v = knob.split("=")
+        monkeypatch.setenv(k, v)
+    got = ColumnEngine(0, path="device_kfast").BGC_SourceSink(*args, z, z, diag_init=-5.0)
+    _same(native, got, knob)
