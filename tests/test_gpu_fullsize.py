@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's full sizes through size-independent properties:
+"""GPU tests at BASELINE.json's full sizes (configs 2, 3 and 4) through size-independent properties:
 determinism, shard invariance (bit-identical per-column results for any batch offset), the
 reference's zero-fill of land / sub-floor cells, conservation of C, N, P, Si (the Jint_*
 integrals vanish to round-off), warm-start consistency of the pH solve, and a strided column
@@ -174,14 +174,20 @@ def test_cfg3_1M_x_60_surface_fluxes_and_tendencies(gpu, oracle, synth):
     assert rep.ok(), "\n".join(rep.fail[:8])
 
 
-def test_large_batch_with_diagnostics_takes_the_fused_schedule(gpu):
-    """Above 10 M cells with diagnostics the library solves the carbonate system inside the cell kernel's wavefronts
-    (DESIGN.md section 4): 400 000 columns x 60 with every diagnostic, against a 640-column window computed on its own
-    (separate carbonate kernel) -- every output bit-identical, conservation to round-off, zero fill below the floor."""
+def test_large_batch_on_the_separate_kernels(gpu, monkeypatch):
+    """The separate attenuation / scan / cell / sweep kernels (OBGC_COLUMN_KERNEL=0) above 10 M cells with diagnostics: the
+    carbonate system is solved inside the cell kernel's wavefronts (schedule 2).  400 000 columns x 60 with every
+    diagnostic, against a 640-column window computed by the default engine (column-block kernel, carbonate kernel beside
+    it) -- every output bit-identical, conservation to round-off, zero fill below the floor."""
     torch, L, eng = gpu
+    from ocean_bgc_amd.engine import Engine
+    monkeypatch.setenv("OBGC_COLUMN_KERNEL", "0")
+    eng_sep = Engine(0)
+    monkeypatch.delenv("OBGC_COLUMN_KERNEL")
     nz, nc = 60, 400_000
-    b = make_batch(torch, L, eng, nz, nc, 0, diag=True)
-    run(L, eng, b)
+    b = make_batch(torch, L, eng_sep, nz, nc, 0, diag=True)
+    run(L, eng_sep, b)
+    assert eng_sep.last_schedule() == 2
     k = torch.arange(nz, device="cuda")[:, None]
     below = k >= b["kmax"][None, :]
     assert torch.isfinite(b["tend"]).all() and (b["tend"][:, below] == 0).all()
@@ -191,10 +197,121 @@ def test_large_batch_with_diagnostics_takes_the_fused_schedule(gpu):
     w0, wn = 333_312, 640
     s = make_batch(torch, L, eng, nz, wn, w0, diag=True)
     run(L, eng, s)
+    assert eng.last_schedule() == 4
     assert torch.equal(s["tend"], b["tend"][:, :, w0:w0 + wn]) and torch.equal(s["ph"], b["ph"][:, :, w0:w0 + wn])
     for nm, v in s["diag"].items():
         assert torch.equal(v, b["diag"][nm][..., w0:w0 + wn]), nm
     del b, s
+    torch.cuda.empty_cache()
+
+
+def make_own(torch, L, eng, b, col0, diag):
+    """DMS / MACROS side of the fused step: own tracers, surface temperature, tendencies, diagnostics (device)."""
+    nz, nc = b["nz"], b["nc"]
+    f64 = dict(dtype=torch.float64, device="cuda")
+    o = dict(own=torch.empty((5, nz, nc), **f64), sst=torch.empty((nc,), **f64), tend=torch.full((5, nz, nc), -7.0, **f64))
+    eng.synth_fill_extra(nz, nc, col0, dms=o["own"][0], dmsp=o["own"][1], prot=o["own"][2], poly=o["own"][3], lip=o["own"][4],
+                         SST=o["sst"])
+    o["dms_diag"] = {nm: torch.full((nz, nc), -7.0, **f64) for nm in L.DMS_DIAG_KC} if diag else None
+    o["macros_diag"] = {nm: torch.full((nz, nc), -7.0, **f64) for nm in L.MACROS_DIAG_KC} if diag else None
+    torch.cuda.synchronize()
+    return o
+
+
+def run_fused(L, eng, b, o):
+    kc, cc, own, t = b["kc"], b["cc"], o["own"], o["tend"]
+    eng.fused_step(b["nz"], b["nc"], L.OBGC_LAYOUT_COLFAST, b["tr"], kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"],
+                   cc["lat"], b["kmax"], kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"], b["tend"], b["ph"][0], b["ph"][1],
+                   b["diag"], True, dms_diag=o["dms_diag"], macros_diag=o["macros_diag"], dms=own[0], dmsp=own[1], SST=o["sst"],
+                   dms_tend=t[0], dmsp_tend=t[1], prot=own[2], poly=own[3], lip=own[4], prot_tend=t[2], poly_tend=t[3],
+                   lip_tend=t[4])
+
+
+def test_cfg4_1M_x_80_fused_step_properties(gpu, oracle, synth):
+    """BASELINE config #4 at full size through obgc_fused_step (BGC + DMS + MACROS, every diagnostic, ~180 GB on the device):
+    finite, deterministic, the reference's zero fill, conservation to round-off, a column window solved on its own
+    bit-identical in EVERY output of the three modules, and a strided column sample against the oracle."""
+    torch, L, eng = gpu
+    torch.cuda.empty_cache()
+    nz, nc = 80, 1_000_000
+    b = make_batch(torch, L, eng, nz, nc, 0, diag=True)
+    o = make_own(torch, L, eng, b, 0, diag=True)
+    run_fused(L, eng, b, o)
+    eng.sync()
+    assert eng.last_schedule() in (3, 4)
+    tend1, own1, ph1 = b["tend"].clone(), o["tend"].clone(), b["ph"].clone()
+    assert torch.isfinite(tend1).all() and torch.isfinite(own1).all() and torch.isfinite(ph1).all()
+    keep = {nm: b["diag"][nm].clone() for nm in ("Jint_Ctot", "zsatcalc", "POC_REMIN", "PAR_avg")}
+    keep_d = o["dms_diag"]["DMS_R_PHOT"].clone()
+    # determinism
+    b["ph"].zero_()
+    torch.cuda.synchronize()               # the engine runs on streams of its own
+    run_fused(L, eng, b, o)
+    eng.sync()
+    assert torch.equal(b["tend"], tend1) and torch.equal(o["tend"], own1) and torch.equal(b["ph"], ph1)
+    for nm, v in keep.items():
+        assert torch.equal(b["diag"][nm], v), nm
+    assert torch.equal(o["dms_diag"]["DMS_R_PHOT"], keep_d)
+    del keep, keep_d
+    # zero fill below the sea floor and on land, in all three modules (BGC_mod.F90:570, DMS_mod.F90:456-468, MACROS_mod.F90:290-299)
+    k = torch.arange(nz, device="cuda")[:, None]
+    below = k >= b["kmax"][None, :]
+    assert (tend1[:, below] == 0).all() and (own1[:, below] == 0).all() and (ph1[:, below] == 0).all()
+    for nm in ("photoC_TOT", "CO3", "POC_REMIN"):
+        assert (b["diag"][nm][below] == 0).all(), nm
+    # DMS and MACROS leave their diagnostics below the floor as they found them (DMS_mod.F90:723-761 and
+    # MACROS_mod.F90:384-402 sit inside the loop over the active levels)
+    assert (o["dms_diag"]["DMS_R_TOTAL"][below] == -7.0).all() and (o["macros_diag"]["PROT_S_TOTAL"][below] == -7.0).all()
+    for nm in L.BGC_DIAG_KC_UNTOUCHED:
+        assert (b["diag"][nm] == -7.0).all()
+    # conservation
+    scale = float(b["diag"]["photoC_TOT_zint"].abs().max())
+    for nm, fac in (("Jint_Ctot", 1.0), ("Jint_Ntot", 0.137), ("Jint_Ptot", 0.00855), ("Jint_Sitot", 0.137)):
+        assert float(b["diag"][nm].abs().max()) <= 1e-10 * scale * fac, nm
+    # a window of 1 000 columns (not a multiple of the 64-column block) on its own: every output of the three modules
+    w0, wn = 765_433, 1_000
+    s = make_batch(torch, L, eng, nz, wn, w0, diag=True)
+    so = make_own(torch, L, eng, s, w0, diag=True)
+    run_fused(L, eng, s, so)
+    eng.sync()
+    assert torch.equal(s["tend"], tend1[:, :, w0:w0 + wn]) and torch.equal(s["ph"], ph1[:, :, w0:w0 + wn])
+    assert torch.equal(so["tend"], own1[:, :, w0:w0 + wn])
+    for nm, v in s["diag"].items():
+        assert torch.equal(v, b["diag"][nm][..., w0:w0 + wn]), nm
+    for grp in ("dms_diag", "macros_diag"):
+        for nm, v in so[grp].items():
+            assert torch.equal(v, o[grp][nm][:, w0:w0 + wn]), nm
+    del s, so
+    # strided sample against the oracle: BGC tendencies and pH, DMS and MACROS tendencies and diagnostics
+    cols = np.arange(0, nc, 3989)
+    sel = torch.as_tensor(cols, device="cuda")
+    h = lambda x: x.index_select(-1, sel).cpu().numpy()
+    tr_h = h(b["tr"]).transpose(0, 2, 1)
+    kc_h = {nm: h(v).T for nm, v in b["kc"].items()}
+    cc_h = {nm: h(v) for nm, v in b["cc"].items()}
+    kmax_h = h(b["kmax"])
+    z = np.zeros((cols.size, nz))
+    want = oracle.bgc_source_sink(tr_h, kc_h["temp"], kc_h["salt"], kc_h["zmid"], kc_h["dz"], kc_h["zbot"], cc_h["lat"], kmax_h,
+                                  kc_h["fesedflux"], cc_h["dust_flux_in"], cc_h["sw_flux"], z, z, diagnostics=False)
+    rep = P.Report()
+    P.compare_tend(rep, "tend", h(tend1).transpose(0, 2, 1), want["tend"])
+    rep.note("ph", "ph_prev", P.e_norm(h(ph1[0]).T, want["ph_prev"]), P.TOL_PH)
+    own_h = h(o["own"]).transpose(0, 2, 1)                       # [5, c, k]
+    named = {nm: tr_h[i] for i, nm in enumerate(L.BGC_TRACERS)}
+    named.update(dms=own_h[0], dmsp=own_h[1], prot=own_h[2], poly=own_h[3], lip=own_h[4])
+    dtr = np.stack([named[nm] for nm in L.DMS_TRACERS])
+    mtr = np.stack([named[nm] for nm in L.MACROS_TRACERS])
+    want_d = oracle.dms_source_sink(dtr, kc_h["dz"], kmax_h, h(o["sst"]), cc_h["sw_flux"], diag_init=-7.0)
+    want_m = oracle.macros_source_sink(mtr, kmax_h, diag_init=-7.0)
+    got_own = h(own1).transpose(0, 2, 1)
+    P.compare_tend(rep, "dms.tend", got_own[0:2], want_d["tend"][0:2])
+    P.compare_tend(rep, "macros.tend", got_own[2:5], want_m["tend"][0:3])
+    for nm, w in want_d["kc"].items():
+        rep.note("diag", "dms.kc." + nm, P.e_norm(h(o["dms_diag"][nm]).T, w), P.TOL_DIAG)
+    for nm, w in want_m["kc"].items():
+        rep.note("diag", "macros.kc." + nm, P.e_norm(h(o["macros_diag"][nm]).T, w), P.TOL_DIAG)
+    assert rep.ok(), "\n".join(rep.fail[:8])
+    del b, o, tend1, own1, ph1
     torch.cuda.empty_cache()
 
 
