@@ -28,12 +28,12 @@ def per_kernel(d):
 
 
 def short(name):
-    for key in ("bgc_carbonate_kernel", "bgc_zsat_kernel", "bgc_att_kernel", "bgc_zint_kernel", "bgc_parscan_kernel",
-                "bgc_surface_kernel", "dms_kernel", "macros_kernel", "transpose_kernel", "bgc_par_kernel",
-                "bgc_cell_kernel", "bgc_sweep_kernel"):
-        if key in name:
-            return key
-    return None
+    """bgc_column_kernel<true, true, 0>(...) in namespaces -> bgc_column_kernel"""
+    import re
+    m = re.search(r"(\w+_kernel)\b", name.replace("(anonymous namespace)::", ""))
+    if not m or not m.group(1).startswith(("bgc_", "fused_", "dms_", "macros_", "transpose_", "apply_", "synth_")):
+        return None
+    return m.group(1)
 
 
 def main():
