@@ -468,7 +468,7 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)      # x ~41 ms: a timed region of 1.2 s
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--diag", default="full", choices=("full", "none"),
