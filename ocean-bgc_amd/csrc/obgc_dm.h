@@ -9,9 +9,13 @@ namespace obgc {
 
 // Morel & Maritorena attenuation across one level from the total chlorophyll (BGC_mod.F90:914-921 and, with the same
 // constants, DMS_mod.F90:541-548): KPARdz
+// The power is taken as exp(e ln w): w >= 0.02, |e ln w| < 3, so the result is within 2-3 ulp of pow()'s -- and ONE
+// logarithm and ONE exponential (~100 fp64 instructions) serve both branches, where two pow() calls with different
+// exponents cost ~200 each and a wavefront that straddles the 0.13224 mg/m3 break executes both.
 __device__ __forceinline__ double kpar_dz_of(double total_chl, double dz) {
   const double w1 = dmax(total_chl, 0.02);
-  const double K = (w1 < 0.13224) ? 0.000919 * pow(w1, 0.3536) : 0.001131 * pow(w1, 0.4562);
+  const bool low = w1 < 0.13224;
+  const double K = (low ? 0.000919 : 0.001131) * exp((low ? 0.3536 : 0.4562) * log(w1));
   return K * dz;
 }
 
@@ -67,7 +71,9 @@ __device__ __forceinline__ void dms_cell_terms(const obgc_dms_params& P, const o
   else
     Rs2n_zoo = (P.Rs2n_diat + P.Rs2n_cocco + P.Rs2n_cyano + P.Rs2n_eukar + P.Rs2n_diaz + P.Rs2n_phaeo) / 6.0;
   const double zooS = Rs2n_zoo * zooN;
-  const double B_diagnosed = P.B_preexp * pow(phytoN, P.B_exp);          // 695
+  // 695: phytoN ** B_exp as exp(B_exp ln phytoN) (half of pow()'s instructions); an empty community keeps pow()'s
+  // conventions for 0 ** x
+  const double B_diagnosed = P.B_preexp * (phytoN > 0.0 ? exp(P.B_exp * log(phytoN)) : pow(phytoN, P.B_exp));
   // kinetics (701-719)
   const double dms_s_dmsp = col.yield * P.k_conv * DMSP;
   const double dms_r_B = P.k_S_B * B_diagnosed * DMS, dms_r_phot = j_dms * DMS, dms_r_bkgnd = P.k_bkgnd * DMS;
