@@ -170,8 +170,9 @@ double obgc_last_kernel_ms(obgc_handle *h, int which);
 /* how the last obgc_bgc_source_sink (or obgc_fused_step) arranged its kernels: 0 the carbonate kernel runs from the
  * start beside the ecosystem kernels, 1 it is released when the cell kernel ends, 2 the carbonate system is solved
  * inside the cell kernel's wavefronts (one launch for both); 3 the column-block kernel (light, cell terms, particle
- * recurrence AND the carbonate system in one launch), 4 the column-block kernel with the carbonate kernel beside it
- * (the default for device pointers in the native layout); -1 before the first call.  Every arrangement gives the
+ * recurrence AND the carbonate system in one launch: the native layout's default above 10 M cells with diagnostics),
+ * 4 the column-block kernel with the carbonate kernel beside it (the native layout's default otherwise); -1 before
+ * the first call.  Every arrangement gives the
  * same bits (measurement harnesses need to know which launch `which = 4` of obgc_last_kernel_ms timed).
  * Environment: OBGC_COLUMN_KERNEL=0 keeps the separate attenuation / scan / cell / sweep kernels (schedules 0-2),
  * OBGC_SCHED=<n> forces an arrangement. */

@@ -456,13 +456,18 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
 // OBGC_SCHED picks when the carbonate kernel is released: 1 (default) when the cell kernel ends, so that its
 // fp64 work overlaps the memory-bound sweep and the cell kernel has the register file to itself; 0 at t = 0;
 // 2 = solved inside the cell kernel's wavefronts (measured slower: two waves per SIMD cannot feed the VALU).
-// The native layout's default: the column-block kernel (attenuation, scan, cell terms and sweep in one launch) on s_main
-// with the carbonate kernel beside it on s_aux from the start (schedule 4: the column kernel leaves VALU issue slots idle
-// while it waits on its stores, 47.7 ms against 51 ms at 1 M columns x 80 levels), then the saturation-horizon scan and
-// the column integrals, which read what the two wrote.  OBGC_SCHED = 1 starts the carbonate kernel when the column kernel
-// ends; OBGC_SCHED = 2 solves the carbonate system inside the column kernel's wavefronts (schedule 3).
+// The native layout's default: the column-block kernel (attenuation, scan, cell terms and sweep in one launch) on s_main,
+// then the saturation-horizon scan and the column integrals, which read what it wrote.  The carbonate system is solved
+//   * by bgc_carbonate_kernel beside it on s_aux from the start of the call (schedule 4): the column kernel leaves VALU
+//     issue slots idle while it waits on memory.  Default up to 10 M cells and whenever no diagnostics are written
+//     (3.07 against 3.23 ms at 100 k columns x 60; 23.96 against 24.39 ms at 1 M x 80 without diagnostics);
+//   * inside the column kernel's wavefronts at the end of every chunk (schedule 3): default above 10 M cells with
+//     diagnostics, where it is 0.5 % ahead (40.4 against 40.7 ms at 1 M x 80, 27.9 against 28.1 ms at 1 M x 60) and the
+//     step is one launch plus its column scans.
+// OBGC_SCHED = 0 forces schedule 4, 1 starts the carbonate kernel when the column kernel ends, 2 forces schedule 3.
 int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F) {
-  const int fuse = (h->sched == 2) ? 1 : 0;
+  const bool large = (long long)K.g.nlev * K.g.ncol > 10000000LL;
+  const int fuse = (h->sched == 2 || (h->sched < 0 && large && K.have_diag)) ? 1 : 0;
   h->last_sched = fuse ? 3 : 4;
   FusedParams fp;
   fp.dms = h->dms;
