@@ -1,4 +1,4 @@
-/* A C host that keeps its tracers on the GPU (INTEGRATION.md section 5): no Python, no PyTorch, only the C ABI of
+/* A C host that keeps its tracers on the GPU: no Python, no PyTorch, only the C ABI of
  * include/obgc.h and the HIP runtime for device memory.
  *
  *   synthetic columns on the device -> 3 x ( BGC_SurfaceFluxes -> BGC_SourceSink -> explicit update )
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   HIP(hipMalloc((void**)&kmax, nc * sizeof(int)));
   if (!tr || !tend || !net) { fprintf(stderr, "device allocation failed\n"); return 1; }
 
-  /* the deterministic workload of SURVEY.md 8d, generated on the device in the native layout */
+  /* the deterministic synthetic workload, generated on the device in the native layout */
   obgc_synth_args sy;
   memset(&sy, 0, sizeof sy);
   sy.nlev = nz; sy.ncol = nc; sy.col0 = 0;

@@ -3,9 +3,9 @@
  * This is the drop-in boundary for the hot path of E3SM-Project/Ocean-BGC: every
  * compute entry point below replaces one public Fortran subroutine of the
  * reference (which has no FFI layer of its own -- its boundary is the Fortran
- * module API, SURVEY.md 8b).  The thin Fortran modules in ocean-bgc_amd/fortran/
+ * module API).  The thin Fortran modules in ocean-bgc_amd/fortran/
  * keep the reference's module and procedure names and forward to these functions
- * through ISO_C_BINDING; INTEGRATION.md shows the binding.
+ * through ISO_C_BINDING.
  *
  *   reference subroutine (file:line)                      C entry point
  *   BGC_parms_init      BGC_parms.F90:497   + BGC_init BGC_mod.F90:184   obgc_bgc_params_init
@@ -335,7 +335,7 @@ typedef struct {
 
 int obgc_fused_step(obgc_handle *h, const obgc_fused_step_args *a);
 
-/* ------------------------------------------- resident tracers (SURVEY.md 8f rank 2)
+/* ------------------------------------------- resident tracers
  * NO reference counterpart: the reference returns tendencies and the host model owns the time
  * integration.  For a host that keeps its tracers on the GPU between steps this is the step right
  * after the path -- an explicit update that avoids moving 60 arrays over PCIe every step:
@@ -360,7 +360,7 @@ typedef struct {
 
 int obgc_apply_tendencies(obgc_handle *h, const obgc_apply_tendencies_args *a);
 
-/* ------------------------------ a mesh block resident on the device (SURVEY.md 8f rank 1 + 2)
+/* ------------------------------ a mesh block resident on the device
  * The device-side twin of ocean-bgc_amd/fortran/obgc_mpas_adapter.F90: a block of an unstructured-mesh ocean model
  * (tracer-fastest arrays in metres, one column per cell) whose BGC state -- native-layout tracers, tendencies,
  * PH_PREV_*, surface_pH* -- lives on the GPU.  Per step only the model's own arrays cross PCIe (tracers, T, S,
@@ -396,7 +396,7 @@ typedef struct {
  * inside the block) */
 int obgc_block_step(obgc_block *b, const obgc_block_step_args *a);
 
-/* --------------------------------------- diagnostics kept on the device (SURVEY.md 8f rank 3)
+/* --------------------------------------- diagnostics kept on the device
  * NO reference counterpart (the host model averages and writes diagnostics).  Diagnostics are 65 % of the bytes
  * the path produces; a host that only needs time means at its output interval keeps both the instantaneous
  * arrays and the running means on the GPU and downloads the means it selected when the interval ends:
@@ -419,7 +419,7 @@ int obgc_accumulate_arrays(obgc_handle *h, const obgc_grid *grid, int nplanes, c
                            double *const *mean_planes, int nvecs, const double *const *inst_vecs,
                            double *const *mean_vecs, double weight, int reset);
 
-/* ------------------------------- parameter files and restart state (SURVEY.md 8f rank 4)
+/* ------------------------------- parameter files and restart state
  * Host-only helpers (no GPU needed).  The reference has no file format: its parameters are module variables.
  * Text format: sections [bgc], [autotroph N], [dms], [macros]; `name = value` with the reference's names; reals
  * are written as C99 hex floats (exact round trip), read as decimal or hex, always in the "C" locale.  Reading only
@@ -447,7 +447,7 @@ int obgc_restart_write_grid(const char *path, const obgc_grid *grid, const doubl
 int obgc_restart_read_grid(const char *path, const obgc_grid *grid, double *ph_prev, double *ph_prev_alt,
                            double *surface_pH, double *surface_pH_alt);
 
-/* ------------------------------------------------ column ranges for several devices (SURVEY.md 8e)
+/* ------------------------------------------------ column ranges for several devices
  * No statement of the path reads another column (BGC_mod.F90:808-814 resets the only carried scalars), so N
  * devices take N contiguous column ranges and exchange nothing.  Host-only helper: bounds[0..nparts] with
  * bounds[0] = 0 <= ... <= bounds[nparts] = ncol; device p owns [bounds[p], bounds[p+1]).
@@ -457,7 +457,7 @@ int obgc_restart_read_grid(const char *path, const obgc_grid *grid, double *ph_p
 int obgc_partition_columns(const int *kmax, long long ncol, int nparts, int balance, long long *bounds);
 
 /* ----------------------------------------------- workload utilities (bench/tests)
- * Deterministic synthetic columns (SURVEY.md 8d), generated on the device in the
+ * Deterministic synthetic columns, generated on the device in the
  * engine's native COLFAST layout for global columns [col0, col0+ncol).  Bit-identical
  * to ocean-bgc_amd/synth.py.  All pointers are DEVICE pointers; NULL skips a field.
  * `tracers` receives 30 planes placed by `ind` (1-based, OBGC_BGC_TRACERS order). */

@@ -795,7 +795,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
     const obgc_bgc_diag& D = *a->diag;
     const bool gaps_c = st.host && v.ldc != v.ncol;
     // every (k,column) diagnostic is written in full (values or the zero fill), so only padding has to be read in first;
-    // the three members neither the reference nor the engine touches do not travel at all
+    // the three members neither the reference nor the engine touches (POC_ACCUM, DONr_remin, DOPr_remin) do not travel at all
 #define X(n)                                                                                          \
   if (D.n) {                                                                                          \
     const bool untouched = &D.n == &D.POC_ACCUM || &D.n == &D.DONr_remin || &D.n == &D.DOPr_remin;   \

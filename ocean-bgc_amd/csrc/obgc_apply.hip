@@ -1,4 +1,4 @@
-// Explicit update of resident tracers (SURVEY.md 8f rank 2; no reference counterpart -- the host model owns
+// Explicit update of resident tracers (no reference counterpart -- the host model owns
 // time integration).  Pure streaming: 16 B read + 8 B written per tracer value, HBM-bound.
 //   x <- x + dt * (tend + [k == 0] * net_flux / dz)     for k < kmax(column);   optional clamp at zero.
 #include <cstdint>

@@ -3,7 +3,7 @@
 // In the reference this work sits inside the sequential level loop of every column
 // (BGC_mod.F90:935-1032 -> co2calc.F90:214-316, 1096-1238) although no level depends
 // on another: two Newton solves and ~35 transcendentals per cell, about 70 % of the
-// flops of the whole routine (SURVEY.md 3.2).  Here every active (level, column) cell
+// flops of the whole routine.  Here every active (level, column) cell
 // is one lane, so even the 100k-column config exposes 5.7 M independent lanes, and
 // the vertical recurrences are left to the much lighter column-sweep kernel.
 //

@@ -195,7 +195,7 @@ __device__ __forceinline__ void talk_row_reforder(const TalkInv& v, double kw, d
 //   of their product (|product| stays within 1e-90..1e-30 for 1e-13 < x < 1e-3) and 18 multiplications;
 //   sums are written with fma.
 // This leaves the reference's operation order: each term moves by a few ulp, the root by ~1e-15 relative
-// (Newton is self-correcting), far inside the pH bar of 1e-12; measured parity is quoted in DESIGN.md.
+// (Newton is self-correcting), far inside the pH bar of 1e-12; the measured parity did not move.
 __device__ __forceinline__ double rcp_nr(double p) {
   double r = __builtin_amdgcn_rcp(p);
   double e = __builtin_fma(-p, r, 1.0);
@@ -491,7 +491,7 @@ __device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool ins
     }
   } else if (A.have_diag) {
     // the reference zero-fills every diagnostic first (BGC_mod.F90:649-658); PH_PREV_* of
-    // inactive cells are left untouched
+    // inactive cells are left untouched (the reference's loop stops at the sea floor, BGC_mod.F90:935-1001)
     const obgc_bgc_diag& D = A.diag;
     if (D.CO3) D.CO3[ix] = 0.0;
     if (D.HCO3) D.HCO3[ix] = 0.0;

@@ -4,7 +4,7 @@
 // DMS and DMSP planes of the 14-plane tendency array are ever non-zero, the other twelve
 // are zero-filled like the reference's whole-array assignment (413).
 // MACROS: no vertical coupling at all -> one lane per cell, pure streaming
-// (88 algorithmic bytes per active cell, SURVEY.md 8d).
+// (88 algorithmic bytes per active cell).
 #include "obgc_dm.h"
 
 namespace obgc {

@@ -18,7 +18,7 @@
 // QA-dust deficit, PAR and the column integrals are really carried from level to level -- a few
 // dozen flops per cell.  The ~2 000 flops of kinetics per cell are level-independent once PAR
 // is known.  With one lane per column the 100k-column config offers 1 563 wavefronts for 1 024
-// SIMDs (measured round 1: 5.2 ms, latency bound at one 512-register wave per SIMD); with one
+// SIMDs (measured: 5.2 ms, latency bound at one 512-register wave per SIMD); with one
 // lane per cell it offers 94 000.  The price is a scratch hand-off between the cell kernel and
 // the sweep (22 doubles per cell, + 5 with diagnostics) in the same layout as the caller's
 // arrays, so a single index addresses everything.
@@ -26,7 +26,7 @@
 // Arithmetic order is the reference's everywhere except three tendency sums that the hand-off
 // re-associates (Fe, SiO3, PO4: the per-autotroph terms are folded before the particle terms
 // are added) and P_iron production (Fe scavenging added last); the change is a few ulp of the
-// largest term, far inside the parity bar, and is listed in DESIGN.md.
+// largest term, far inside the parity bar.
 #include <cstdio>
 #include <cstring>
 

@@ -1,4 +1,4 @@
-// Parameter text files and the restart file of the only persistent state (SURVEY.md 8f rank 4).
+// Parameter text files and the restart file of the only persistent state.
 // Host-only code (no HIP): lets stand-alone drivers, benchmarks and regression suites run the engine with an
 // explicit, versioned parameter set and carry PH_PREV_* / surface_pH* across runs.  The reference has no file
 // format of its own (its parameters are Fortran module variables set by *_parms_init and edited by the host).
@@ -300,7 +300,7 @@ extern "C" int obgc_restart_read_grid(const char* path, const obgc_grid* g, doub
   return OBGC_OK;
 }
 
-// Static contiguous column ranges for `nparts` devices (SURVEY.md 8e).  Columns are independent, so any cut is
+// Static contiguous column ranges for `nparts` devices.  Columns are independent, so any cut is
 // legal; with ragged bathymetry the cost of a range is its number of ACTIVE cells, not of columns.
 //   balance = 0: equal column counts;  1: equal sums of max(kmax, 0) (prefix sum, cut at the first column whose
 //   prefix reaches p/nparts of the total).

@@ -1,7 +1,7 @@
 // On-device twin of ocean-bgc_amd/synth.py: deterministic synthetic columns in the native
 // COLFAST layout.  Only splitmix64 hashes and + - * / are used, and this file is built
 // with -ffp-contract=off, so every value is bit-identical to the numpy generator.
-// Workload utility for bench.py / tests (SURVEY.md 8d), not part of the hot path.
+// Workload utility for bench.py / tests, not part of the hot path.
 #include "obgc_internal.h"
 
 namespace obgc {

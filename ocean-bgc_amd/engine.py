@@ -270,7 +270,7 @@ class Engine:
 
     def apply_tendencies(self, nlev, ncol, layout, tracers, tend, kmax, dt, net_flux=None, dz=None, clamp_nonneg=False,
                          ld=0, plane=0, ldc=0):
-        """x <- x + dt*(tend + [k==1]*net_flux/dz) on device-resident tracers."""
+        """x <- x + dt*(tend + [k==1]*net_flux/dz) on device-resident tracers (no reference routine: the host model owns the time integration)."""
         ms = self._memspace(tracers)
         a = L.ApplyTendenciesArgs()
         a.grid = make_grid(nlev, ncol, layout, ms, ld, plane, ldc)

@@ -1,6 +1,6 @@
 """Python mirror of the reference's module API on top of the GPU engine.
 
-The reference's call surface (SURVEY.md 8b) is
+The reference's call surface is
 
     BGC_parms_init / BGC_init / BGC_SourceSink / BGC_SurfaceFluxes      (BGC_mod.F90:106-110)
     DMS_parms_init / DMS_init / DMS_SourceSink / DMS_SurfaceFluxes      (DMS_mod.F90:51-55)
@@ -37,7 +37,7 @@ class ColumnEngine:
         self.path = path
         self.device = device
         self.eng = Engine(device)
-        # *_parms_init followed by *_init, as the host must call them
+        # *_parms_init followed by *_init, as the host must call them (BGC_parms.F90:497, BGC_mod.F90:184)
         self.eng.set_bgc_indices(bgc_indices, T0_Kelvin)
         self.eng.set_dms_indices(dms_indices)
         self.eng.set_macros_indices(macros_indices)
@@ -235,7 +235,7 @@ class ColumnEngine:
         return dict(forcing={nm: dn(v, "c") for nm, v in f.items()}, netFlux=dn(netf, "c"),
                     fdiag={nm: dn(v, "c") for nm, v in fd.items()})
 
-    # ---- resident tracers (SURVEY.md 8f rank 2; no reference routine) ----
+    # ---- resident tracers (no reference routine) ----
     def apply_tendencies(self, tracers, tend, kmax, dt, net_flux=None, dz=None, clamp_nonneg=False):
         """Returns x + dt*(tend + [k==1]*net_flux/dz) computed on the device (device paths only)."""
         if self.path == "host":

@@ -1,6 +1,6 @@
 """Deterministic synthetic column generator (host / numpy twin of csrc/synth.hip).
 
-Follows the recipe of SURVEY.md 8d: every value is a closed-form function of the
+Every value is a closed-form function of the
 GLOBAL column index c, the level k and a field id, through splitmix64 hashes and
 +,-,*,/ only (no transcendentals), so the numpy version here and the on-device
 version produce bit-identical inputs, any shard of columns can be generated

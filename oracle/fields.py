@@ -37,7 +37,7 @@ BGC_DIAG_KC = [
     "calcToSed", "pocToSed", "ponToSed", "popToSed", "bsiToSed", "dustToSed",
     "pfeToSed", "SedDenitrif", "OtherRemin", "tot_CaCO3_form",
 ]
-# never touched by the reference
+# never touched by the reference (POC_ACCUM, DONr_remin, DOPr_remin have no assignment in BGC_mod.F90)
 BGC_DIAG_KC_UNTOUCHED = ["POC_ACCUM", "DONr_remin", "DOPr_remin"]
 
 # (k,column,autotroph)

@@ -10,7 +10,7 @@
 #include <math.h>
 #include <string.h>
 
-/* Branch counters (SURVEY.md 8d "branches the data must hit"): every BR() marks one arm of a data-dependent
+/* Branch counters (the arms of every data-dependent branch the workload must reach): every BR() marks one arm of a data-dependent
  * branch of the reference; tests assert that the synthetic workload reaches all of them.  Thread-local, so the
  * restatement stays re-entrant. */
 enum { BR_zero_mask, BR_gQfe_limited, BR_gQsi_fe_limited, BR_gQsi_fe_zero, BR_gQsi_si_limited, BR_kpar_low, BR_kpar_high, BR_ph_cold, BR_ph_warm, BR_zsat_found, BR_zsat_never, BR_q10_below_thres, BR_mmrt_north, BR_mmrt_south, BR_caco3_cold, BR_caco3_bloom, BR_zumax_taper_north, BR_zumax_taper_south, BR_par_avg_dark, BR_fe_scav_high, BR_nitrif_active, BR_nitrif_taper, BR_o2_lt5, BR_o2_5_40, BR_scalelen_top, BR_scalelen_mid, BR_scalelen_deep, BR_qa_def_consumed, BR_qa_def_remains, BR_poc_hflux_zero, BR_iron_clamp, BR_bottom_flux, BR_bottom_no3_lt5, BR_bottom_o2_lt1, BR_bottom_sio2_fast, BR_bottom_above_lysocline, BR_newton_bracket_grow, BR_newton_bisect, BR_newton_step, BR_newton_exit_same, BR_newton_exit_xacc, BR_COUNT };
@@ -1648,7 +1648,7 @@ void ora_macros_source_sink(const ora_macros_params *p, int nz, int nc, const do
 #undef DK
 }
 
-/* SURVEY.md 8f rank 2 (no reference counterpart; see obgc_oracle.h) */
+/* explicit update of resident tracers (no reference counterpart; see obgc_oracle.h) */
 void ora_apply_tendencies(int nz, int nc, int ntracer, double *tracers, const double *tend, const double *net_flux,
                           const double *dz, const int *kmax, double dt, int clamp_nonneg) {
   const size_t plane = (size_t)nz * nc;

@@ -208,7 +208,7 @@ const char *ora_branch_name(int i);
 unsigned long long ora_branch_hit(int i);
 void ora_branch_reset(void);
 
-/* SURVEY.md 8f rank 2, explicit update of resident tracers.  PARITY UNPINNED: the reference has no such routine
+/* Explicit update of resident tracers.  PARITY UNPINNED: the reference has no such routine
  * (the host model integrates in time); this is the plain statement of the formula in include/obgc.h, in the
  * reference's array layout:  x(k,c,n) += dt*(tend(k,c,n) + [k==1]*net_flux(c,n)/dz(1,c)),  k <= kmax(c). */
 void ora_apply_tendencies(int nz, int nc, int ntracer, double *tracers, const double *tend, const double *net_flux,

@@ -198,7 +198,7 @@ class Oracle:
         return dict(forcing={nm: frc[i] for i, nm in enumerate(F.DMS_SURF_FORCING)}, netFlux=netf,
                     fdiag={nm: fd[i] for i, nm in enumerate(F.DMS_FLUX_DIAG)})
 
-    # ---- branch-coverage counters (SURVEY.md 8d) ----------------------------------
+    # ---- branch-coverage counters ----------------------------------
     def branch_reset(self):
         self.lib.ora_branch_reset()
 

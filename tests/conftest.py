@@ -65,7 +65,7 @@ def has_gpu():
         return False
 
 
-# ---- parity metrics of SURVEY.md 8d ------------------------------------------
+# ---- parity metrics ------------------------------------------
 def e_norm(x, xref):
     m = np.abs(xref).max()
     d = np.abs(np.asarray(x) - np.asarray(xref)).max()

@@ -1,4 +1,4 @@
-"""Hand-made columns for the branch arms the synthetic generator (SURVEY.md 8d) never reaches.
+"""Hand-made columns for the branch arms the synthetic generator never reaches.
 
     column 0   previous pH far from the root (5.0): the Newton bracket has to grow (co2calc.F90:920-938)
     column 1   heavy dust over almost no biomass: the QA dust deficit survives a level (BGC_mod.F90:2390-2410)

@@ -9,7 +9,7 @@ Fixtures are DATA: seeded synthetic inputs (ocean-bgc_amd/synth.py) for a handfu
 branch-coverage columns and every output array the reference produced for them.
 
   config1_1x60.npz       BASELINE config #1: 1 column x 60 levels, every module
-  branch_cols_60.npz     24 columns x 60 levels chosen to hit the branches of SURVEY 8d
+  branch_cols_60.npz     24 columns x 60 levels chosen to hit every data-dependent branch of the path
   branch_cols_100.npz    8 columns x 100 levels (crosses 3300 m lysocline test, BGC_mod.F90:2564)
   branch_cols_80.npz     12 columns x 80 levels: the level count of BASELINE config #4 (BGC + DMS + MACROS)
 

@@ -1,4 +1,4 @@
-"""Parity bars of SURVEY.md 8d / BASELINE.md, shared by the GPU tests, smoke() and bench.py.
+"""Parity bars shared by the GPU tests, smoke() and bench.py.
 
 Per output array X:  e_norm = max|X - Xref| / max|Xref|   and
                      e_pt   = max over |Xref| > 1e-6 max|Xref| of |X - Xref| / |Xref|.
@@ -11,7 +11,7 @@ Per output array X:  e_norm = max|X - Xref| / max|Xref|   and
                                              are ~0 by construction (sources - sinks), so only an
                                              absolute bar is meaningful
 
-The bars sit 3 orders above the reference's own FMA-vs-no-FMA spread.
+The bars sit 3 orders above the reference's own FMA-vs-no-FMA spread (measured by building the reference with and without contraction).
 """
 import numpy as np
 

@@ -1,4 +1,4 @@
-"""explicit update of device-resident tracers (obgc_apply_tendencies).
+"""Explicit update of device-resident tracers (obgc_apply_tendencies).
 
 There is no reference routine for this step (the host model integrates in time), so the oracle function is the
 plain statement of the formula in include/obgc.h -- "parity unpinned" by construction.  What is pinned:

@@ -1,4 +1,4 @@
-"""SURVEY.md 8d "branches the data must hit": counters in the CPU restatement (oracle/obgc_oracle.c, BR(...)) assert
+"""The branches the data must hit: counters in the CPU restatement (oracle/obgc_oracle.c, BR(...)) assert
 that the synthetic workload plus four hand-made columns (tests/crafted.py) drive every data-dependent arm of
 BGC_SourceSink / co2calc the scope table lists; the hand-made columns are also pinned against the unmodified
 reference (bit for bit) and, on the GPU, against the oracle at the parity bars.
@@ -28,7 +28,7 @@ def test_workload_reaches_every_branch(oracle, synth):
         tr = synth.bgc_tracer_array(syn)
         z = np.zeros((nc, nz))
         w = oracle.bgc_source_sink(tr, *_args(syn), z, z)
-        if nz == 60:     # secondary timing mode of SURVEY.md 8d: warm brackets on perturbed tracers
+        if nz == 60:     # the secondary timing mode: warm brackets on perturbed tracers
             oracle.bgc_source_sink(tr * 1.001, *_args(syn), w["ph_prev"], w["ph_prev_alt"])
     generator_only = oracle.branch_hits()
     syn, php = crafted_columns(synth)

@@ -1,4 +1,4 @@
-"""running time means of the diagnostics kept on the device (obgc_bgc_diag_accumulate).
+"""Running time means of the diagnostics kept on the device (obgc_bgc_diag_accumulate).
 
 No reference counterpart (the host model averages its diagnostics), so parity is unpinned by construction; the
 statement checked is  mean <- (reset ? 0 : mean) + w * inst  per member, bit for bit against numpy, for every

@@ -108,7 +108,7 @@ def test_error_paths_return_a_status_and_a_message(pkg, synth):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["device_colfast", "host"])
 def test_poisoned_columns_stay_in_their_lane(engines, synth, path):
-    """The reference cannot fail: bad input (NaN tracers, a zero-thickness level -> 0/0, SURVEY.md 8b) silently
+    """The reference cannot fail: bad input (NaN tracers, a zero-thickness level -> 0/0) silently
     poisons its own column.  The engine must do the same: return, not hang in the Newton loops, and leave every
     other column's bits exactly as they are without the bad neighbours."""
     E = engines[path]

@@ -1,4 +1,4 @@
-"""The engine driven from the library's own files, on the GPU (SURVEY.md 8f rank 4):
+"""The engine driven from the library's own files, on the GPU:
 
   * a parameter file written by obgc_params_write_text, read back by obgc_params_read_text, pushed with
     obgc_set_*_params, run by the kernels, compared with the oracle given the same table;

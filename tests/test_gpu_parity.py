@@ -46,7 +46,7 @@ def test_bgc_source_sink_vs_reference_golden(engines, path, fixture):
     z = np.zeros((nc, nz))
     a = E.BGC_SourceSink(g["in.bgc_tracers"], *bgc_common(g), z, z, alt_co2_use_eco=True, diag_init=-7.0)
     _assert(P.compare_bgc(a, P.golden_bgc(g, "bgc_cold")), "%s cold %s" % (fixture, path))
-    for nm in F.BGC_DIAG_KC_UNTOUCHED:
+    for nm in F.BGC_DIAG_KC_UNTOUCHED:                      # never assigned by the reference
         assert (a["kc"][nm] == -7.0).all(), nm
     # cells below the sea floor: tendencies and diagnostics are zero, PH_PREV untouched (quirk 11)
     km = g["in.kmax"]

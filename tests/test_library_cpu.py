@@ -123,7 +123,7 @@ def test_product_never_touches_the_oracle():
 
 
 def test_partition_columns(L):
-    """obgc_partition_columns (SURVEY.md 8e): contiguous ranges that tile the columns; with balance=cells no
+    """obgc_partition_columns: contiguous ranges that tile the columns; with balance=cells no
     range exceeds the mean number of active cells by more than one column's worth."""
     from ocean_bgc_amd.engine import ObgcError, partition_columns
     rng = np.random.default_rng(3)

@@ -1,4 +1,4 @@
-"""the batched MPAS-style host adapter (ocean-bgc_amd/fortran/obgc_mpas_adapter.F90).
+"""The batched MPAS-style host adapter (ocean-bgc_amd/fortran/obgc_mpas_adapter.F90).
 
 The adapter only uses the reference's Fortran module API, so the SAME source is linked twice:
   * oracle/_ref/test_mpas_adapter_ref   against the unmodified reference objects (CPU, built by `make -C oracle

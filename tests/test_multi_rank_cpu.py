@@ -1,6 +1,6 @@
 """world_size-2 `gloo` test of the N>1 path on CPU: the static column-range partition of bench.py,
 its max/sum reductions, and shard invariance (a column's result does not depend on which rank or
-batch offset it lands on -- there is no collective on the data path, SURVEY.md 8e)."""
+batch offset it lands on -- there is no collective on the data path)."""
 import os
 import sys
 

@@ -2,7 +2,7 @@
 fixtures produced by the UNMODIFIED reference (tests/golden/make_golden.py).
 
 The oracle is compiled without FMA contraction exactly like the reference, and in
-practice reproduces it bit for bit; the asserted bar is the one DESIGN.md states for
+practice reproduces it bit for bit; the asserted bar is the one tests/parity.py states for
 oracle-vs-reference (e_norm <= 1e-14), with integer-like fields exact.
 """
 import os
@@ -118,7 +118,7 @@ def test_known_answers(oracle):
                                 np.full(n, 1.0))
     for nm, v in one.items():
         check("co2calc_1point." + nm, v, g["co2calc_1point." + nm])
-    # Newton work: warm bracket needs far fewer talk_row evaluations than the cold one (SURVEY 3.2)
+    # Newton work: warm bracket needs far fewer talk_row evaluations than the cold one
     assert w["talk_calls"] < c["talk_calls"]
 
 
@@ -129,6 +129,6 @@ def test_parameter_tables_match_reference_dump(oracle):
         assert np.array_equal(p[key], g[key]), key
     assert np.array_equal(oracle.dms_get_parms(), g["dms_parms"])
     assert np.array_equal(oracle.macros_get_parms(), g["macros_parms"])
-    # SURVEY 8a quirk 2: single-precision literals widened to double
+    # single-precision literals widened to double
     assert g["consts"][0] == np.float64(np.float32(1.0e-8))
     assert g["consts"][1] == np.float64(np.float32(3.17e-8))

@@ -1,4 +1,4 @@
-"""parameter text files and the restart file (host-only helpers of libobgc.so, no GPU)."""
+"""Parameter text files and the restart file (host-only helpers of libobgc.so, no GPU)."""
 import ctypes as C
 
 import numpy as np

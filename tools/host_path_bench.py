@@ -1,4 +1,4 @@
-# DESIGN.md section 6: PCIe-inclusive host-memory path at cfg2 size.  python tools/host_path_bench.py
+# PCIe-inclusive host-memory path at cfg2 size.  python tools/host_path_bench.py
 # PCIe-inclusive rate: host (numpy) arrays in the reference layout through the C ABI, cfg2 size
 import sys, time, numpy as np
 sys.path.insert(0,'.'); from __graft_entry__ import load_pkg; load_pkg()

@@ -1,4 +1,4 @@
-# worst-case differences GPU vs oracle, 20 000 columns x 60, all outputs of BGC_SourceSink.
+# Worst-case differences GPU vs oracle, 20 000 columns x 60, all outputs of BGC_SourceSink.
 # python tools/parity_summary.py   (on an MI355X; the oracle is test infrastructure and only checks here)
 import os, sys
 import numpy as np

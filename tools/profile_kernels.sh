@@ -1,5 +1,5 @@
 #!/bin/bash
-# Measurement scripts behind the numbers in DESIGN.md; run from the repository root on an MI355X (e.g. through gpurun).
+# Measurement script (kernel stats and HBM traffic of the 100 000-column workload); run from the repository root on an MI355X (e.g. through gpurun).
 
 # kernel stats + HBM traffic (separate PMC passes) for the current kernel revision
 cd /tmp && export TMPDIR=/tmp

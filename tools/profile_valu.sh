@@ -1,5 +1,5 @@
 #!/bin/bash
-# Measurement scripts behind the numbers in DESIGN.md; run from the repository root on an MI355X (e.g. through gpurun).
+# Measurement script (fp64 VALU utilisation per kernel); run from the repository root on an MI355X (e.g. through gpurun).
 
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

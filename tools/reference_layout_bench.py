@@ -1,4 +1,4 @@
-# device-resident reference (level-fastest) layout at cfg2 size -- hybrid vs all-transposes vs strides.
+# Device-resident reference (level-fastest) layout at cfg2 size -- hybrid vs all-transposes vs strides.
 # Run from the repository root on an MI355X:  python tools/reference_layout_bench.py
 # device-resident REFERENCE layout (Fortran k-fastest) at cfg2 size: tiled-transpose path vs generic strides
 import os, sys, time, torch

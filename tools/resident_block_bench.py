@@ -1,4 +1,4 @@
-# one step of a device-resident mesh block (obgc_block_step) at cfg2 size, PCIe-inclusive:
+# One step of a device-resident mesh block (obgc_block_step) at cfg2 size, PCIe-inclusive:
 # only the model's arrays cross the link.  python tools/resident_block_bench.py
 import ctypes as C, os, sys, time
 import numpy as np

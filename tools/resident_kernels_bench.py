@@ -1,4 +1,4 @@
-# bandwidth of obgc_apply_tendencies and obgc_bgc_diag_accumulate.  python tools/resident_kernels_bench.py [ncol]
+# Bandwidth of obgc_apply_tendencies and obgc_bgc_diag_accumulate.  python tools/resident_kernels_bench.py [ncol]
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_pkg
