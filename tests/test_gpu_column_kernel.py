@@ -114,3 +114,26 @@ def test_reference_layout_forms_match_native(pkg, synth, monkeypatch, knob):
         monkeypatch.setenv(k, v)
     got = ColumnEngine(0, path="device_kfast").BGC_SourceSink(*args, z, z, diag_init=-5.0)
     _same(native, got, knob)
+
+
+@pytest.mark.parametrize("nz", [1, 2, 3, 5, 9])
+def test_tiny_columns_and_partial_blocks(pkg, synth, monkeypatch, nz):
+    """Level counts below, at and just above one 4-level chunk; column counts around one 64-column block; land columns
+    (kmax = 0) in between: the chunk loop, the rotating walk and the masked lanes against the separate kernels, bit for bit,
+    BGC alone and with the DMS / MACROS terms."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    old, new = _engines(monkeypatch)
+    for nc in (1, 63, 65, 130):
+        syn = synth.generate(nc, nz, col0=900 + nc)
+        syn["kmax"][::7] = 0                                  # land
+        tr, dtr, mtr = synth.bgc_tracer_array(syn), synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)
+        args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+                syn["sw"])
+        z = np.zeros((nc, nz))
+        _same(old.BGC_SourceSink(*args, z, z, diag_init=-5.0), new.BGC_SourceSink(*args, z, z, diag_init=-5.0), "bgc %d x %d" % (nc, nz))
+        sst = syn["forcing"]["SST"]
+        a = old.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0)
+        b = new.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0)
+        for part in ("bgc", "dms", "macros"):
+            _same(a[part], b[part], "%s %d x %d" % (part, nc, nz))
