@@ -562,12 +562,13 @@ def main():
             del w
             torch.cuda.empty_cache()
             extras = {}
-            for key, (name, ph, st) in {"headline_warm_ph": (args.config, "warm" if args.ph == "cold" else "cold", 5),
-                                        "cfg2": ("cfg2", "cold", 10), "cfg3": ("cfg3", "cold", 5)}.items():
-                if key != "headline_warm_ph" and name == args.config:
+            for key, (name, ph, st, dg) in {"headline_warm_ph": (args.config, "warm" if args.ph == "cold" else "cold", 5, diag_on),
+                                            "headline_other_diag_mode": (args.config, args.ph, 5, not diag_on),
+                                            "cfg2": ("cfg2", "cold", 10, diag_on), "cfg3": ("cfg3", "cold", 5, diag_on)}.items():
+                if not key.startswith("headline") and name == args.config:
                     continue
                 try:
-                    extras[key] = short_run(eng, torch, L, name, diag_on, ph, st, 2, not args.separate)
+                    extras[key] = short_run(eng, torch, L, name, dg, ph, st, 2, not args.separate)
                 except Exception as exc:      # never lose the headline over an extra
                     extras[key] = {"failed": repr(exc)}
             out["other_workloads"] = extras

@@ -797,11 +797,11 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     // autotroph tendencies (1676-1697)
     wk = gz + loss + ag;
     const double t_C = photoC - wk;
-    TEND(t.C_ind) = t_C;
-    TEND(t.Chl_ind) = photoacc - thetaC * wk;
-    TEND(t.Fe_ind) = photoFe - Qfe * wk;
-    if (t.Si_ind > 0) { const double v = photoSi - Qsi * wk; TEND(t.Si_ind) = v; sSi = sSi + v; }
-    if (t.CaCO3_ind > 0) { const double v = CaProd - QCa * wk; TEND(t.CaCO3_ind) = v; sCa = sCa + v; }
+    OBGC_STORE(&TEND(t.C_ind), t_C);
+    OBGC_STORE(&TEND(t.Chl_ind), photoacc - thetaC * wk);
+    OBGC_STORE(&TEND(t.Fe_ind), photoFe - Qfe * wk);
+    if (t.Si_ind > 0) { const double v = photoSi - Qsi * wk; OBGC_STORE(&TEND(t.Si_ind), v); sSi = sSi + v; }
+    if (t.CaCO3_ind > 0) { const double v = CaProd - QCa * wk; OBGC_STORE(&TEND(t.CaCO3_ind), v); sCa = sCa + v; }
     if (DIAG) {
       ST_KCA(auto_graze, a, gz); ST_KCA(auto_loss, a, loss); ST_KCA(auto_agg, a, ag);
       sC = sC + t_C; sQpC = sQpC + t.Qp * t_C; sNfix = sNfix + Nfix; chl = chl + p.Chl;
@@ -836,11 +836,11 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
   const double t_doc = DOC_prod - DOC_remin;
   const double t_don = (DON_prod * (1.0 - DONREFRACT)) - DON_remin;
   const double t_dop = (DOP_prod * (1.0 - DOPREFRACT)) - DOP_remin - sDOPV;
-  TEND(P.ind[15]) = t_zooC;
-  TEND(P.ind[9]) = t_doc;
-  TEND(P.ind[10]) = t_don;
-  TEND(P.ind[11]) = DOFe_prod - DOFe_remin;
-  TEND(P.ind[12]) = t_dop;
+  OBGC_STORE(&TEND(P.ind[15]), t_zooC);
+  OBGC_STORE(&TEND(P.ind[9]), t_doc);
+  OBGC_STORE(&TEND(P.ind[10]), t_don);
+  OBGC_STORE(&TEND(P.ind[11]), DOFe_prod - DOFe_remin);
+  OBGC_STORE(&TEND(P.ind[12]), t_dop);
   // ---- particle-dependent tendencies: everything local is folded here and waits in the caller's
   //      tendency plane; the sweep adds the remineralisation terms (listed with each line) ----
   const double L_no3 = (NITRIF - sNO3V) - D0;                                             // 1583: - wd*((reminPOC-OTHER)/C - SED) - SED
@@ -865,8 +865,8 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     ho[H_DEC_POC][tid] = dv.decay_POC_E; ho[H_DEC_SI][tid] = dv.decay_SiO2; ho[H_DEC_CA][tid] = dv.decay_CaCO3;
     ho[H_DEC_DUST][tid] = dv.decay_dust; ho[H_DEC_HARD][tid] = dv.DECAY_Hard; ho[H_DEC_HARDDUST][tid] = dv.DECAY_HardDust;
   } else {
-    TEND(P.ind[1]) = L_no3; TEND(P.ind[3]) = L_nh4; TEND(P.ind[4]) = L_fe; TEND(P.ind[2]) = L_sio3; TEND(P.ind[0]) = L_po4;
-    TEND(P.ind[14]) = L_donr; TEND(P.ind[13]) = L_dopr; TEND(P.ind[6]) = L_dic; TEND(P.ind[8]) = L_alk; TEND(P.ind[5]) = L_o2;
+    OBGC_STORE(&TEND(P.ind[1]), L_no3); OBGC_STORE(&TEND(P.ind[3]), L_nh4); OBGC_STORE(&TEND(P.ind[4]), L_fe); OBGC_STORE(&TEND(P.ind[2]), L_sio3); OBGC_STORE(&TEND(P.ind[0]), L_po4);
+    OBGC_STORE(&TEND(P.ind[14]), L_donr); OBGC_STORE(&TEND(P.ind[13]), L_dopr); OBGC_STORE(&TEND(P.ind[6]), L_dic); OBGC_STORE(&TEND(P.ind[8]), L_alk); OBGC_STORE(&TEND(P.ind[5]), L_o2);
   }
 
   if (DIAG) {
@@ -1127,17 +1127,17 @@ __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obg
   double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
   wo = dmin(dmax(wo, 0.0), 1.0);
   const double oc_p = wo * ((reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN) / REMIN_D_C_O2);
-  TEND(P.ind[1], ix) = t_no3;
-  TEND(P.ind[3], ix) = t_nh4;
-  TEND(P.ind[4], ix) = t_fe;
-  TEND(P.ind[2], ix) = t_sio3;
-  TEND(P.ind[0], ix) = t_po4;
-  TEND(P.ind[14], ix) = t_donr;
-  TEND(P.ind[13], ix) = t_dopr;
-  TEND(P.ind[6], ix) = t_dic;
-  TEND(P.ind[7], ix) = A.alt_co2_use_eco ? t_dic : 0.0;
-  TEND(P.ind[8], ix) = t_alk;
-  TEND(P.ind[5], ix) = cur.L_o2 - oc_p;
+  OBGC_STORE(&TEND(P.ind[1], ix), t_no3);
+  OBGC_STORE(&TEND(P.ind[3], ix), t_nh4);
+  OBGC_STORE(&TEND(P.ind[4], ix), t_fe);
+  OBGC_STORE(&TEND(P.ind[2], ix), t_sio3);
+  OBGC_STORE(&TEND(P.ind[0], ix), t_po4);
+  OBGC_STORE(&TEND(P.ind[14], ix), t_donr);
+  OBGC_STORE(&TEND(P.ind[13], ix), t_dopr);
+  OBGC_STORE(&TEND(P.ind[6], ix), t_dic);
+  OBGC_STORE(&TEND(P.ind[7], ix), A.alt_co2_use_eco ? t_dic : 0.0);
+  OBGC_STORE(&TEND(P.ind[8], ix), t_alk);
+  OBGC_STORE(&TEND(P.ind[5], ix), cur.L_o2 - oc_p);
 
   JTerms jt{0.0, 0.0, 0.0, 0.0};
   if (DIAG) {   // 2637-2694, 1563-1577, 1866-1868
@@ -1352,6 +1352,10 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     OBGC_T(3);   // the walk (one wavefront per chunk)
     lds_barrier();   // the recurrence has passed the chunk
     OBGC_T(4);
+    // The carbonate block's nine inputs are requested HERE, ahead of the stores of the finish phase: vector memory
+    // operations complete in issue order, so requested behind them they would wait for every one of them.
+    CarbIn cin;
+    if (FUSE) carbonate_load(*Ap, Pp->ind[6], Pp->ind[8], Pp->ind[0], Pp->ind[2], X.valid, X.k, X.valid ? c : 0, cin);
     if (active) {
       const int t = threadIdx.x;
       const long long ix = g.at(X.k, c);
@@ -1382,7 +1386,7 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     }
     OBGC_T(5);   // finish
     // no barrier here: the next chunk's first write into the slots sits behind its light barrier
-    if (FUSE) carbonate_cell(*Ap, Pp->ind[6], Pp->ind[8], Pp->ind[0], Pp->ind[2], X.valid, X.k, X.valid ? c : 0);
+    if (FUSE) carbonate_solve(*Ap, X.valid, X.k, cin);
     OBGC_T(6);
   }
 #ifdef OBGC_COLTIMING
