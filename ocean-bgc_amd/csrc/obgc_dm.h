@@ -42,8 +42,9 @@ template <bool DIAG>
 __device__ __forceinline__ void dms_cell_terms(const obgc_dms_params& P, const obgc_dms_diag& D, long long ix, const DmsColumn& col,
                                                double DMS, double DMSP, double zooC, double spC, double spCaCO3, double diatC,
                                                double diazC, double phaeoC, double spChl, double PAR_avg, double& t_dms,
-                                               double& t_dmsp) {
-#define ST(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
+                                               double& t_dmsp, bool live = true) {
+// live = false: a lane below the sea floor that runs along (column-block kernel); the reference leaves these diagnostics alone there
+#define ST(name, v) do { if (DIAG && live && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
   const double k_S_p = P.k_S_p_base * (P.mort + (zooC / 0.3));          // 529: hard-wired 0.3, not zooC_avg
   const double j_dms = P.j_dms_perI * PAR_avg;
   // community partition (570-612)
@@ -101,7 +102,7 @@ __device__ __forceinline__ void dms_cell_terms(const obgc_dms_params& P, const o
 template <bool DIAG>
 __device__ __forceinline__ void macros_cell_terms(const obgc_macros_params& P, const obgc_macros_diag& D, long long ix, double zooC,
                                                   double spC, double diatC, double diazC, double phaeoC, double PROT, double POLY,
-                                                  double LIP, double& t_prot, double& t_poly, double& t_lip) {
+                                                  double LIP, double& t_prot, double& t_poly, double& t_lip, bool live = true) {
   const double k_C_p = P.k_C_p_base * (P.mort + (zooC / P.zooC_avg));                  // 349
   const double phytoC = diatC + phaeoC + spC + diazC;                                   // 366
   const double prot_s = P.inject_scale * P.f_prot * k_C_p * phytoC;                     // 372-378
@@ -111,7 +112,7 @@ __device__ __forceinline__ void macros_cell_terms(const obgc_macros_params& P, c
   t_prot = prot_s - prot_r;
   t_poly = poly_s - poly_r;
   t_lip = lip_s - lip_r;
-  if (DIAG) {
+  if (DIAG && live) {
     if (D.PROT_S_TOTAL) D.PROT_S_TOTAL[ix] = prot_s;
     if (D.POLY_S_TOTAL) D.POLY_S_TOTAL[ix] = poly_s;
     if (D.LIP_S_TOTAL) D.LIP_S_TOTAL[ix] = lip_s;

@@ -421,8 +421,14 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
 #define RAW(slot) A.tracers[(long long)((slot)-1) * pl + ix]
 #define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
 #define SCR(s) A.scratch[(long long)(s) * A.splane + ix]
-#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
-#define ST_KCA(name, a, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[(long long)(a) * pl + ix], (v)); } while (0)
+// Column-block kernel: a lane whose cell lies below the sea floor runs the same statements on whatever its arrays hold there
+// and stores the reference's zero fill through the SAME store instructions (Z(v) = 0 for it).  A wavefront that straddles the
+// floor -- one in five at 1 M x 80 -- then issues every store once, over full 512-byte rows, instead of once per side.
+#define Z(v) ((COLK && !live) ? 0.0 : (v))
+#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
+#define ST_KCA(name, a, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[(long long)(a) * pl + ix], Z(v)); } while (0)
+#define ST_TEND(slot, v) OBGC_STORE(&TEND(slot), Z(v))
+  bool live = true;
   int kmax = in.kmax;
   bool dflag = in.dflag;
   const double lat = in.lat, T = in.T, dz = in.dz, zc = in.zc;
@@ -466,9 +472,10 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       dflag = true;   // DMS always takes its own (usually identical) numbers here
     }
     if (!X->valid) return false;
+    live = k < kmax;
   }
 
-  if (k >= kmax) {
+  if (!COLK && k >= kmax) {
     // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727; DMS_mod.F90:413,
     // MACROS_mod.F90:267 for the tendencies of the other two modules, whose diagnostics it leaves alone)
     if (DM) {
@@ -518,17 +525,17 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       const DmsColumn col = dms_column_terms(FP->dms, o_sst);
       double t_dms, t_dmsp;
       dms_cell_terms<true>(FP->dms, F->ddiag, ix, col, dmax(0.0, o_dms), dmax(0.0, o_dmsp), c_zoo, c_sp, dmax(0.0, o_spca), c_diat,
-                           c_diaz, c_phaeo, dmax(0.0, pick_Chl(raw, P.sp_ind - 1)), PAR_avg_dms, t_dms, t_dmsp);
-      F->dms_tend[ix] = t_dms;
-      F->dmsp_tend[ix] = t_dmsp;
+                           c_diaz, c_phaeo, dmax(0.0, pick_Chl(raw, P.sp_ind - 1)), PAR_avg_dms, t_dms, t_dmsp, live);
+      F->dms_tend[ix] = Z(t_dms);
+      F->dmsp_tend[ix] = Z(t_dmsp);
     }
     if (F->prot) {
       double t_prot, t_poly, t_lip;
       macros_cell_terms<true>(FP->macros, F->mdiag, ix, c_zoo, c_sp, c_diat, c_diaz, c_phaeo, dmax(0.0, o_prot), dmax(0.0, o_poly),
-                              dmax(0.0, o_lip), t_prot, t_poly, t_lip);
-      F->prot_tend[ix] = t_prot;
-      F->poly_tend[ix] = t_poly;
-      F->lip_tend[ix] = t_lip;
+                              dmax(0.0, o_lip), t_prot, t_poly, t_lip, live);
+      F->prot_tend[ix] = Z(t_prot);
+      F->poly_tend[ix] = Z(t_poly);
+      F->lip_tend[ix] = Z(t_lip);
     }
   }
 
@@ -733,10 +740,10 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       d_totCa = d_totCa + cp;
     }
     if (DIAG) {   // the sweep integrates these four profiles; caller's arrays or scratch
-      A.z_photoC[(long long)a * pl + ix] = photoC;
-      A.z_photoC_NO3[(long long)a * pl + ix] = pC_NO3;
-      A.z_CaCO3_form[(long long)a * pl + ix] = CaProd;
-      A.z_bSi_form[(long long)a * pl + ix] = photoSi;
+      A.z_photoC[(long long)a * pl + ix] = Z(photoC);
+      A.z_photoC_NO3[(long long)a * pl + ix] = Z(pC_NO3);
+      A.z_CaCO3_form[(long long)a * pl + ix] = Z(CaProd);
+      A.z_bSi_form[(long long)a * pl + ix] = Z(photoSi);
     }
     // losses (1285-1290)
     const double loss = t.mort * Pp * Tfunc;
@@ -797,11 +804,11 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     // autotroph tendencies (1676-1697)
     wk = gz + loss + ag;
     const double t_C = photoC - wk;
-    OBGC_STORE(&TEND(t.C_ind), t_C);
-    OBGC_STORE(&TEND(t.Chl_ind), photoacc - thetaC * wk);
-    OBGC_STORE(&TEND(t.Fe_ind), photoFe - Qfe * wk);
-    if (t.Si_ind > 0) { const double v = photoSi - Qsi * wk; OBGC_STORE(&TEND(t.Si_ind), v); sSi = sSi + v; }
-    if (t.CaCO3_ind > 0) { const double v = CaProd - QCa * wk; OBGC_STORE(&TEND(t.CaCO3_ind), v); sCa = sCa + v; }
+    ST_TEND(t.C_ind, t_C);
+    ST_TEND(t.Chl_ind, photoacc - thetaC * wk);
+    ST_TEND(t.Fe_ind, photoFe - Qfe * wk);
+    if (t.Si_ind > 0) { const double v = photoSi - Qsi * wk; ST_TEND(t.Si_ind, v); sSi = sSi + v; }
+    if (t.CaCO3_ind > 0) { const double v = CaProd - QCa * wk; ST_TEND(t.CaCO3_ind, v); sCa = sCa + v; }
     if (DIAG) {
       ST_KCA(auto_graze, a, gz); ST_KCA(auto_loss, a, loss); ST_KCA(auto_agg, a, ag);
       sC = sC + t_C; sQpC = sQpC + t.Qp * t_C; sNfix = sNfix + Nfix; chl = chl + p.Chl;
@@ -836,11 +843,11 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
   const double t_doc = DOC_prod - DOC_remin;
   const double t_don = (DON_prod * (1.0 - DONREFRACT)) - DON_remin;
   const double t_dop = (DOP_prod * (1.0 - DOPREFRACT)) - DOP_remin - sDOPV;
-  OBGC_STORE(&TEND(P.ind[15]), t_zooC);
-  OBGC_STORE(&TEND(P.ind[9]), t_doc);
-  OBGC_STORE(&TEND(P.ind[10]), t_don);
-  OBGC_STORE(&TEND(P.ind[11]), DOFe_prod - DOFe_remin);
-  OBGC_STORE(&TEND(P.ind[12]), t_dop);
+  ST_TEND(P.ind[15], t_zooC);
+  ST_TEND(P.ind[9], t_doc);
+  ST_TEND(P.ind[10], t_don);
+  ST_TEND(P.ind[11], DOFe_prod - DOFe_remin);
+  ST_TEND(P.ind[12], t_dop);
   // ---- particle-dependent tendencies: everything local is folded here and waits in the caller's
   //      tendency plane; the sweep adds the remineralisation terms (listed with each line) ----
   const double L_no3 = (NITRIF - sNO3V) - D0;                                             // 1583: - wd*((reminPOC-OTHER)/C - SED) - SED
@@ -865,8 +872,8 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     ho[H_DEC_POC][tid] = dv.decay_POC_E; ho[H_DEC_SI][tid] = dv.decay_SiO2; ho[H_DEC_CA][tid] = dv.decay_CaCO3;
     ho[H_DEC_DUST][tid] = dv.decay_dust; ho[H_DEC_HARD][tid] = dv.DECAY_Hard; ho[H_DEC_HARDDUST][tid] = dv.DECAY_HardDust;
   } else {
-    OBGC_STORE(&TEND(P.ind[1]), L_no3); OBGC_STORE(&TEND(P.ind[3]), L_nh4); OBGC_STORE(&TEND(P.ind[4]), L_fe); OBGC_STORE(&TEND(P.ind[2]), L_sio3); OBGC_STORE(&TEND(P.ind[0]), L_po4);
-    OBGC_STORE(&TEND(P.ind[14]), L_donr); OBGC_STORE(&TEND(P.ind[13]), L_dopr); OBGC_STORE(&TEND(P.ind[6]), L_dic); OBGC_STORE(&TEND(P.ind[8]), L_alk); OBGC_STORE(&TEND(P.ind[5]), L_o2);
+    ST_TEND(P.ind[1], L_no3); ST_TEND(P.ind[3], L_nh4); ST_TEND(P.ind[4], L_fe); ST_TEND(P.ind[2], L_sio3); ST_TEND(P.ind[0], L_po4);
+    ST_TEND(P.ind[14], L_donr); ST_TEND(P.ind[13], L_dopr); ST_TEND(P.ind[6], L_dic); ST_TEND(P.ind[8], L_alk); ST_TEND(P.ind[5], L_o2);
   }
 
   if (DIAG) {
@@ -887,6 +894,8 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
 #undef SCR
 #undef ST_KC
 #undef ST_KCA
+#undef ST_TEND
+#undef Z
 }
 
 // FUSE = 1: the wavefront goes on to solve the carbonate system of its own cells (obgc_co2.h) after the
@@ -1100,11 +1109,12 @@ struct JTerms { double C, N, P, Si; };
 // tendencies and 27 diagnostics (1569-1577, 1583-1790, 2637-2694).  Stores go to the caller's arrays at index ix.
 template <bool DIAG>
 __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, const LevelIn<DIAG>& cur,
-                                               const SweepCoreOut& o) {
+                                               const SweepCoreOut& o, bool live = true) {
   const obgc_bgc_diag& D = A.diag;
   const long long pl = A.g.plane;
 #define TEND(slot, ix) A.tend[(long long)((slot)-1) * pl + (ix)]
-#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
+#define Z(v) (live ? (v) : 0.0)      // a cell below the sea floor (column-block kernel only): the reference's zero fill
+#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
   const double dz = cur.dz, NO3 = dmax(0.0, cur.NO3), O2 = dmax(0.0, cur.O2);
   const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
   const double reminPOC = o.reminPOC, reminCa = o.reminCa, reminSi = o.reminSi, reminFe = o.reminFe, Fe_scavenge = o.Fe_scavenge,
@@ -1127,17 +1137,17 @@ __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obg
   double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
   wo = dmin(dmax(wo, 0.0), 1.0);
   const double oc_p = wo * ((reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN) / REMIN_D_C_O2);
-  OBGC_STORE(&TEND(P.ind[1], ix), t_no3);
-  OBGC_STORE(&TEND(P.ind[3], ix), t_nh4);
-  OBGC_STORE(&TEND(P.ind[4], ix), t_fe);
-  OBGC_STORE(&TEND(P.ind[2], ix), t_sio3);
-  OBGC_STORE(&TEND(P.ind[0], ix), t_po4);
-  OBGC_STORE(&TEND(P.ind[14], ix), t_donr);
-  OBGC_STORE(&TEND(P.ind[13], ix), t_dopr);
-  OBGC_STORE(&TEND(P.ind[6], ix), t_dic);
-  OBGC_STORE(&TEND(P.ind[7], ix), A.alt_co2_use_eco ? t_dic : 0.0);
-  OBGC_STORE(&TEND(P.ind[8], ix), t_alk);
-  OBGC_STORE(&TEND(P.ind[5], ix), cur.L_o2 - oc_p);
+  OBGC_STORE(&TEND(P.ind[1], ix), Z(t_no3));
+  OBGC_STORE(&TEND(P.ind[3], ix), Z(t_nh4));
+  OBGC_STORE(&TEND(P.ind[4], ix), Z(t_fe));
+  OBGC_STORE(&TEND(P.ind[2], ix), Z(t_sio3));
+  OBGC_STORE(&TEND(P.ind[0], ix), Z(t_po4));
+  OBGC_STORE(&TEND(P.ind[14], ix), Z(t_donr));
+  OBGC_STORE(&TEND(P.ind[13], ix), Z(t_dopr));
+  OBGC_STORE(&TEND(P.ind[6], ix), Z(t_dic));
+  OBGC_STORE(&TEND(P.ind[7], ix), Z(A.alt_co2_use_eco ? t_dic : 0.0));
+  OBGC_STORE(&TEND(P.ind[8], ix), Z(t_alk));
+  OBGC_STORE(&TEND(P.ind[5], ix), Z(cur.L_o2 - oc_p));
 
   JTerms jt{0.0, 0.0, 0.0, 0.0};
   if (DIAG) {   // 2637-2694, 1563-1577, 1866-1868
@@ -1162,6 +1172,7 @@ __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obg
   return jt;
 #undef TEND
 #undef ST_KC
+#undef Z
 }
 
 // conservation integrals (1870-1938), top to bottom; J[0..7] = C, C 100 m, N, N 100 m, P, P 100 m, Si, Si 100 m
@@ -1372,7 +1383,7 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
       lo.L_no3 = s_ho[H_L_NO3][t]; lo.L_nh4 = s_ho[H_L_NH4][t]; lo.L_fe = s_ho[H_L_FE][t]; lo.L_sio3 = s_ho[H_L_SIO3][t];
       lo.L_po4 = s_ho[H_L_PO4][t]; lo.L_donr = s_ho[H_L_DONR][t]; lo.L_dopr = s_ho[H_L_DOPR][t]; lo.L_dic = s_ho[H_L_DIC][t];
       lo.L_alk = s_ho[H_L_ALK][t]; lo.L_o2 = s_ho[H_L_O2][t];
-      const JTerms jt = sweep_finish<DIAG>(*Ap, *Pp, ix, lo, o);
+      const JTerms jt = sweep_finish<DIAG>(*Ap, *Pp, ix, lo, o, X.k < kmax);
       if (DIAG) {
         // integrands of the conservation integrals: summed top to bottom by the column-integral kernel
         double* jw = Ap->jw;
