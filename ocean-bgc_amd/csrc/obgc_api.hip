@@ -460,10 +460,10 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
 // then the saturation-horizon scan and the column integrals, which read what it wrote.  The carbonate system is solved
 //   * by bgc_carbonate_kernel beside it on s_aux from the start of the call (schedule 4): the column kernel leaves VALU
 //     issue slots idle while it waits on memory.  Default up to 10 M cells and whenever no diagnostics are written
-//     (3.07 against 3.23 ms at 100 k columns x 60; 23.96 against 24.39 ms at 1 M x 80 without diagnostics);
+//     (2.79 against 3.02 ms at 100 k columns x 60; 23.5 against 23.7 ms at 1 M x 80 without diagnostics);
 //   * inside the column kernel's wavefronts at the end of every chunk (schedule 3): default above 10 M cells with
-//     diagnostics, where it is 0.5 % ahead (40.4 against 40.7 ms at 1 M x 80, 27.9 against 28.1 ms at 1 M x 60) and the
-//     step is one launch plus its column scans.
+//     diagnostics, where the two tie (38.0-38.2 against 37.6-38.0 ms at 1 M x 80, 26.1 against 26.3 ms at 1 M x 60) and
+//     this form is one launch plus its column scans and leaves s_aux idle.
 // OBGC_SCHED = 0 forces schedule 4, 1 starts the carbonate kernel when the column kernel ends, 2 forces schedule 3.
 int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F) {
   const bool large = (long long)K.g.nlev * K.g.ncol > 10000000LL;
