@@ -17,12 +17,6 @@
 
 using namespace obgc;
 
-// (k,column) diagnostics written by bgc_sweep_kernel (the others come from the cell and carbonate kernels)
-#define OBGC_SWEEP_DIAG_KC(X) \
-  X(POC_FLUX_IN) X(POC_PROD) X(POC_REMIN) X(CaCO3_FLUX_IN) X(CaCO3_PROD) X(CaCO3_REMIN) X(SiO2_FLUX_IN) X(SiO2_PROD) \
-  X(SiO2_REMIN) X(dust_FLUX_IN) X(dust_REMIN) X(P_iron_FLUX_IN) X(P_iron_PROD) X(P_iron_REMIN) X(calcToSed) X(bsiToSed) \
-  X(pocToSed) X(SedDenitrif) X(OtherRemin) X(ponToSed) X(popToSed) X(dustToSed) X(pfeToSed) X(DENITRIF) X(O2_CONSUMPTION) \
-  X(Fe_scavenge) X(Fe_scavenge_rate)
 
 
 namespace {

@@ -421,10 +421,12 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
 #define RAW(slot) A.tracers[(long long)((slot)-1) * pl + ix]
 #define TEND(slot) A.tend[(long long)((slot)-1) * pl + ix]
 #define SCR(s) A.scratch[(long long)(s) * A.splane + ix]
-// Column-block kernel: a lane whose cell lies below the sea floor runs the same statements on whatever its arrays hold there
-// and stores the reference's zero fill through the SAME store instructions (Z(v) = 0 for it).  A wavefront that straddles the
-// floor -- one in five at 1 M x 80 -- then issues every store once, over full 512-byte rows, instead of once per side.
-#define Z(v) ((COLK && !live) ? 0.0 : (v))
+// A lane whose cell lies below the sea floor (or on land) runs the same statements on whatever its arrays hold there and
+// stores the reference's zero fill of tendencies and diagnostics (BGC_mod.F90:570, 625-727; DMS_mod.F90:413 and
+// MACROS_mod.F90:267 for the tendencies of the other two modules, whose diagnostics the reference leaves alone) through the
+// SAME store instructions: Z(v) = 0 for it.  A wavefront that straddles the floor -- one in five at 1 M x 80 -- then issues
+// every store once, over full rows, instead of once per side of the floor.
+#define Z(v) (live ? (v) : 0.0)
 #define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
 #define ST_KCA(name, a, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[(long long)(a) * pl + ix], Z(v)); } while (0)
 #define ST_TEND(slot, v) OBGC_STORE(&TEND(slot), Z(v))
@@ -472,37 +474,18 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       dflag = true;   // DMS always takes its own (usually identical) numbers here
     }
     if (!X->valid) return false;
-    live = k < kmax;
+  }
+  live = k < kmax;
+  if (!COLK && !live) {
+    // separate kernels: the sweep only visits cells above the floor, so what only IT writes gets the zero fill here
+    TEND(P.ind[7]) = 0.0;
+    if (DIAG) {
+#define X(n) if (D.n) D.n[ix] = 0.0;
+      OBGC_SWEEP_DIAG_KC(X)
+#undef X
+    }
   }
 
-  if (!COLK && k >= kmax) {
-    // below the sea floor / land: the reference zero-fills tendencies and diagnostics (570, 625-727; DMS_mod.F90:413,
-    // MACROS_mod.F90:267 for the tendencies of the other two modules, whose diagnostics it leaves alone)
-    if (DM) {
-      if (F->dms) { F->dms_tend[ix] = 0.0; F->dmsp_tend[ix] = 0.0; }
-      if (F->prot) { F->prot_tend[ix] = 0.0; F->poly_tend[ix] = 0.0; F->lip_tend[ix] = 0.0; }
-    }
-#pragma unroll 6
-    for (int n = 0; n < OBGC_BGC_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
-    if (DIAG) {
-#define ZKC(n) if (D.n) D.n[ix] = 0.0;
-      ZKC(tot_Nfix) ZKC(O2_PRODUCTION) ZKC(O2_CONSUMPTION) ZKC(AOU) ZKC(PO4_RESTORE) ZKC(NO3_RESTORE) ZKC(SiO3_RESTORE)
-      ZKC(PAR_avg) ZKC(POC_FLUX_IN) ZKC(POC_PROD) ZKC(POC_REMIN) ZKC(CaCO3_FLUX_IN) ZKC(CaCO3_PROD) ZKC(CaCO3_REMIN)
-      ZKC(SiO2_FLUX_IN) ZKC(SiO2_PROD) ZKC(SiO2_REMIN) ZKC(dust_FLUX_IN) ZKC(dust_REMIN) ZKC(P_iron_FLUX_IN)
-      ZKC(P_iron_PROD) ZKC(P_iron_REMIN) ZKC(auto_graze_TOT) ZKC(zoo_loss) ZKC(photoC_TOT) ZKC(photoC_NO3_TOT)
-      ZKC(DOC_prod) ZKC(DOC_remin) ZKC(DON_prod) ZKC(DON_remin) ZKC(DOFe_prod) ZKC(DOFe_remin) ZKC(DOP_prod)
-      ZKC(DOP_remin) ZKC(Fe_scavenge) ZKC(Fe_scavenge_rate) ZKC(NITRIF) ZKC(DENITRIF) ZKC(calcToSed) ZKC(pocToSed)
-      ZKC(ponToSed) ZKC(popToSed) ZKC(bsiToSed) ZKC(dustToSed) ZKC(pfeToSed) ZKC(SedDenitrif) ZKC(OtherRemin)
-      ZKC(tot_CaCO3_form)
-#undef ZKC
-#define ZKCA(n) if (D.n) { D.n[ix] = 0.0; D.n[pl + ix] = 0.0; D.n[2 * pl + ix] = 0.0; D.n[3 * pl + ix] = 0.0; }
-      ZKCA(N_lim) ZKCA(P_lim) ZKCA(Fe_lim) ZKCA(SiO3_lim) ZKCA(light_lim) ZKCA(photoC) ZKCA(photoC_NO3) ZKCA(photoFe)
-      ZKCA(photoNO3) ZKCA(photoNH4) ZKCA(DOP_uptake) ZKCA(PO4_uptake) ZKCA(auto_graze) ZKCA(auto_loss) ZKCA(auto_agg)
-      ZKCA(bSi_form) ZKCA(CaCO3_form) ZKCA(Nfix)
-#undef ZKCA
-    }
-    return false;
-  }
 
   const double T0K = P.T0_Kelvin_BGC;
   const bool north = lat >= 0.0, south_or_eq = lat <= 0.0;

@@ -10,6 +10,14 @@
 // (-3.5 % on the column-block kernel at 1 M columns x 80 levels with every diagnostic; the same bits)
 #define OBGC_STORE(p, v) __builtin_nontemporal_store((v), (p))
 
+// (k,column) diagnostics written by the particle part of the path (bgc_sweep_kernel / the finish phase of the column-block
+// kernel); the others come from the cell terms and the carbonate block
+#define OBGC_SWEEP_DIAG_KC(X) \
+  X(POC_FLUX_IN) X(POC_PROD) X(POC_REMIN) X(CaCO3_FLUX_IN) X(CaCO3_PROD) X(CaCO3_REMIN) X(SiO2_FLUX_IN) X(SiO2_PROD) \
+  X(SiO2_REMIN) X(dust_FLUX_IN) X(dust_REMIN) X(P_iron_FLUX_IN) X(P_iron_PROD) X(P_iron_REMIN) X(calcToSed) X(bsiToSed) \
+  X(pocToSed) X(SedDenitrif) X(OtherRemin) X(ponToSed) X(popToSed) X(dustToSed) X(pfeToSed) X(DENITRIF) X(O2_CONSUMPTION) \
+  X(Fe_scavenge) X(Fe_scavenge_rate)
+
 namespace obgc {
 
 // Strided view of the level-dependent arrays of one call.  Element (k, c) of plane n
