@@ -66,22 +66,21 @@ __global__ __launch_bounds__(kBlockCell) void dms_cell_kernel(const DmsKernelArg
   else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
   const long long ix = g.at(k, c), pl = g.plane;
   const obgc_dms_diag& D = A.diag;
-  if (k >= A.kmax[c]) {   // the reference zero-fills the tendencies of the whole array first
-#pragma unroll
-    for (int n = 0; n < OBGC_DMS_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
-    return;
-  }
+  // A cell below the sea floor runs along on whatever its arrays hold and stores zeros: one store pass per wavefront, also
+  // where it straddles the floor (the reference zero-fills the tendencies of the whole array first, DMS_mod.F90:413, and
+  // leaves the diagnostics below the floor alone)
+  const bool live = k < A.kmax[c];
   const DmsColumn col = dms_column_terms(P, A.SST[c]);
   const double DMS = TRD(0, ix), DMSP = TRD(1, ix), zooC = TRD(4, ix), spC = TRD(5, ix), spCaCO3 = TRD(6, ix), diatC = TRD(7, ix),
                diazC = TRD(8, ix), phaeoC = TRD(9, ix), spChl = TRD(10, ix);
   const double PAR_in = A.s_parin[ix], att = A.s_att[ix], KPARdz = A.s_kpardz[ix];
   const double PAR_avg = PAR_in * (1.0 - att) / KPARdz;
   double t_dms, t_dmsp;
-  dms_cell_terms<DIAG>(P, D, ix, col, DMS, DMSP, zooC, spC, spCaCO3, diatC, diazC, phaeoC, spChl, PAR_avg, t_dms, t_dmsp);
+  dms_cell_terms<DIAG>(P, D, ix, col, DMS, DMSP, zooC, spC, spCaCO3, diatC, diazC, phaeoC, spChl, PAR_avg, t_dms, t_dmsp, live);
+  const int n_dms = P.ind[0] - 1, n_dmsp = P.ind[1] - 1;
 #pragma unroll
-  for (int n = 0; n < OBGC_DMS_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;
-  A.tend[(long long)(P.ind[0] - 1) * pl + ix] = t_dms;
-  A.tend[(long long)(P.ind[1] - 1) * pl + ix] = t_dmsp;
+  for (int n = 0; n < OBGC_DMS_NTRACER; ++n)
+    A.tend[(long long)n * pl + ix] = (live && n == n_dms) ? t_dms : (live && n == n_dmsp) ? t_dmsp : 0.0;
 }
 
 #undef TRD
@@ -97,15 +96,14 @@ __global__ __launch_bounds__(kBlockCell) void macros_kernel(const MacrosKernelAr
   else { c = (int)(idx % g.ncol); k = (int)(idx / g.ncol); }
   const long long ix = g.at(k, c), pl = g.plane;
   const obgc_macros_diag& D = A.diag;
-#pragma unroll
-  for (int n = 0; n < OBGC_MACROS_NTRACER; ++n) A.tend[(long long)n * pl + ix] = 0.0;   // MACROS_mod.F90:267
-  if (k >= A.kmax[c]) return;
+  const bool live = k < A.kmax[c];   // below the floor: zeros through the same stores (MACROS_mod.F90:267), diagnostics left alone
 #define TRM(j) dmax(0.0, A.tracers[(long long)(P.ind[j] - 1) * pl + ix])
   double t_prot, t_poly, t_lip;
-  macros_cell_terms<DIAG>(P, D, ix, TRM(3), TRM(4), TRM(5), TRM(6), TRM(7), TRM(0), TRM(1), TRM(2), t_prot, t_poly, t_lip);
-  A.tend[(long long)(P.ind[0] - 1) * pl + ix] = t_prot;
-  A.tend[(long long)(P.ind[1] - 1) * pl + ix] = t_poly;
-  A.tend[(long long)(P.ind[2] - 1) * pl + ix] = t_lip;
+  macros_cell_terms<DIAG>(P, D, ix, TRM(3), TRM(4), TRM(5), TRM(6), TRM(7), TRM(0), TRM(1), TRM(2), t_prot, t_poly, t_lip, live);
+  const int n_prot = P.ind[0] - 1, n_poly = P.ind[1] - 1, n_lip = P.ind[2] - 1;
+#pragma unroll
+  for (int n = 0; n < OBGC_MACROS_NTRACER; ++n)
+    A.tend[(long long)n * pl + ix] = !live ? 0.0 : (n == n_prot) ? t_prot : (n == n_poly) ? t_poly : (n == n_lip) ? t_lip : 0.0;
 #undef TRM
 }
 
