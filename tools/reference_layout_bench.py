@@ -31,6 +31,6 @@ def run(tag, env):
         print(tag, name, "ms/step %.2f" % (1e3*min(ts[1:])), flush=True)
     eng.close()
 run("kfast hybrid         ", {"OBGC_KFAST_DIRECT":"0", "OBGC_KFAST_HYBRID":"1"})
-if os.environ.get("OBGC_BENCH_HYBRID_ONLY", "0") != "1":     # tools/profile_configs.sh profiles the shipped scheme alone
+if os.environ.get("OBGC_BENCH_HYBRID_ONLY", "0") != "1":     # set to 1 to time the shipped scheme alone
     run("kfast all-transposes ", {"OBGC_KFAST_DIRECT":"0", "OBGC_KFAST_HYBRID":"0"})
     run("kfast generic strides", {"OBGC_KFAST_DIRECT":"1"})
