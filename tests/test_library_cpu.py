@@ -147,3 +147,24 @@ def test_partition_columns(L):
     assert partition_columns(np.zeros(0, dtype=np.int32), 3, "cells") == [0, 0, 0, 0]
     with pytest.raises(ObgcError):
         partition_columns(kmax, 0, "cells")
+
+
+def test_fortran_binding_covers_the_resident_and_fused_entry_points():
+    """The generated ISO_C_BINDING module must declare, with the C struct's member order, every entry point the Fortran
+    host with resident tracers uses (no GPU needed: text of the generated module against the header)."""
+    import re
+    api = open(os.path.join(ROOT, "ocean-bgc_amd", "fortran", "obgc_c_api.F90")).read()
+    hdr = open(os.path.join(ROOT, "include", "obgc.h")).read()
+    for fn in ("obgc_fused_step", "obgc_synth_fill", "obgc_synth_fill_extra", "obgc_apply_tendencies", "obgc_last_schedule",
+               "obgc_last_kernel_ms", "obgc_bgc_surface_fluxes", "obgc_bgc_source_sink", "obgc_dms_source_sink_noalloc"):
+        assert re.search(r"bind\(C, name='%s'\)" % fn, api), fn
+        assert re.search(r"\b%s\s*\(" % fn, hdr), fn
+    # member order of the fused-step block: C header vs Fortran type (pointers only, so the order is the layout)
+    c_body = re.search(r"typedef struct \{([^}]*)\} obgc_fused_step_args;", hdr).group(1)
+    c_names = re.findall(r"\*\s*(\w+)", re.sub(r"/\*.*?\*/", "", c_body, flags=re.S))
+    f_body = re.search(r"type, bind\(C\) :: obgc_fused_step_args(.*?)end type", api, re.S).group(1).replace("&\n", " ")
+    f_names = [n.strip() for ln in f_body.splitlines() if "type(c_ptr)" in ln for n in ln.split("::")[1].split(",")]
+    assert c_names == f_names, (c_names, f_names)
+    dev = open(os.path.join(ROOT, "ocean-bgc_amd", "fortran", "obgc_device.F90")).read()
+    for name in ("hipMalloc", "hipFree", "hipMemcpy", "hipMemset"):
+        assert "bind(C, name='%s')" % name in dev
