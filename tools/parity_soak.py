@@ -1,5 +1,6 @@
 # A wider net than the test-suite casts: GPU vs oracle over many blocks of synthetic columns (cold call, then a warm call on
-# perturbed tracers with the previous pH), 60 and 100 levels, worst case per class.  ~2 minutes, mostly oracle time.
+# perturbed tracers with the previous pH), 60, 80 and 100 levels, worst case per class.  The cold call is the fused
+# BGC + DMS + MACROS step (the headline path), the warm call BGC_SourceSink alone.  ~2 minutes for 8 blocks, mostly oracle time.
 # python tools/parity_soak.py [blocks]      (on an MI355X; the oracle only checks here)
 import os, sys
 import numpy as np
@@ -15,13 +16,21 @@ nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 E, O = ColumnEngine(0, path="device_colfast"), orabind.Oracle()
 worst, bad = {}, 0
 for b in range(nblocks):
-    nz = 100 if b % 3 == 2 else 60
+    nz = (60, 80, 100)[b % 3]
     nc, col0 = 8000, 1_000_003 * b + 17
     syn = synth.generate(nc, nz, col0=col0)
     tr = synth.bgc_tracer_array(syn)
     rest = (syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"], syn["sw"])
     z = np.zeros((nc, nz))
-    g1, o1 = E.BGC_SourceSink(tr, *rest, z, z), O.bgc_source_sink(tr, *rest, z, z)
+    dtr, mtr, sst = synth.dms_tracer_array(syn), synth.macros_tracer_array(syn), syn["forcing"]["SST"]
+    fused = E.Fused_SourceSink(tr, *rest, z, z, sst, dtr, mtr)
+    g1, o1 = fused["bgc"], O.bgc_source_sink(tr, *rest, z, z)
+    rep_dm = P.compare_simple(fused["dms"], O.dms_source_sink(dtr, syn["dz"], syn["kmax"], sst, syn["sw"]), "dms")
+    P.compare_simple(fused["macros"], O.macros_source_sink(mtr, syn["kmax"]), "macros", rep_dm)
+    bad += 0 if rep_dm.ok() else 1
+    for k, v in rep_dm.summary().items():
+        if v["max"] >= worst.get("dm_" + k, (-1.0, ""))[0]:
+            worst["dm_" + k] = (v["max"], "%s block %d (fused, col0=%d, nz=%d)" % (v["at"], b, col0, nz))
     tr2 = tr * (1.0 + 1e-3 * np.cos(np.arange(tr.size).reshape(tr.shape)))
     # warm call: both sides start from the ORACLE's previous pH, so the brackets are identical
     g2 = E.BGC_SourceSink(tr2, *rest, o1["ph_prev"], o1["ph_prev_alt"], alt_co2_use_eco=False)
