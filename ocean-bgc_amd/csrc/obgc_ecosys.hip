@@ -1,32 +1,36 @@
-// Ecosystem source/sink terms of BGC_SourceSink as four kernels:
+// Ecosystem source/sink terms of BGC_SourceSink (and, for obgc_fused_step, the cell terms of DMS_SourceSink and
+// MACROS_SourceSink), in two forms that share their device functions statement for statement and give the same bits:
 //
-//   bgc_att_kernel     1 lane / cell     attenuation exp(-KPARdz) of every level (pow + exp)
+//   native (column-fastest) layout -- ONE launch:
+//   bgc_column_kernel  64 columns x 4 levels / workgroup, marching down the columns; lane = column, wavefront = level.
+//                      Light and the particle recurrence are carried through LDS (see the comment above the kernel).
+//
+//   reference (level-fastest) layout, or OBGC_COLUMN_KERNEL=0 -- four kernels with hand-off planes in global memory:
+//   bgc_att_kernel     1 lane / cell     attenuation exp(-KPARdz) of every level
 //   bgc_parscan_kernel 1 lane / column   PAR entering every level: one multiply per level
-//   bgc_cell_kernel    1 lane / cell     every cell-local term: quotas, uptake, photoadaptation,
-//                                        grazing, mortality, DOM, the PRODUCTION terms and decay
-//                                        factors of the sinking particles, 19 final tendencies
-//   bgc_sweep_kernel   1 lane / column   the Armstrong ballast recurrence top to bottom, iron
-//                                        scavenging, sea-floor burial, and the 11 tendencies and
-//                                        the column integrals that depend on it
+//   bgc_cell_kernel    1 lane / cell     every cell-local term: quotas, uptake, photoadaptation, grazing, mortality, DOM,
+//                                        the PRODUCTION terms of the sinking particles, 19 final tendencies and the local
+//                                        part of 10 more
+//   bgc_sweep_kernel   1 lane / column   the Armstrong ballast recurrence top to bottom, iron scavenging, sea-floor burial,
+//                                        and the 11 tendencies and the conservation integrals that depend on it
+//   (fused_att_kernel / fused_parscan_kernel / fused_cell_kernel: the same with the DMS / MACROS terms)
 //
-// Behavioural contract = BGC_mod.F90:733-931 (clamps, zero-mask, quotas, light), 1041-1529
-// (kinetics), 1531-1536 -> 2116-2699 (particles), 1545-1968 (tendencies, diagnostics, column
-// integrals, O2 minimum), 2006-2109 (particle initialisation).  The carbonate block 935-1032
-// is a separate cell-parallel kernel (obgc_carbonate.hip).
+//   bgc_zint_kernel    1 lane / column   column integrals of the production profiles, O2 minimum, Jint_* (both forms)
 //
-// Why three: the reference walks each column sequentially, but only the particle fluxes, the
-// QA-dust deficit, PAR and the column integrals are really carried from level to level -- a few
-// dozen flops per cell.  The ~2 000 flops of kinetics per cell are level-independent once PAR
-// is known.  With one lane per column the 100k-column config offers 1 563 wavefronts for 1 024
-// SIMDs (measured: 5.2 ms, latency bound at one 512-register wave per SIMD); with one
-// lane per cell it offers 94 000.  The price is a scratch hand-off between the cell kernel and
-// the sweep (22 doubles per cell, + 5 with diagnostics) in the same layout as the caller's
-// arrays, so a single index addresses everything.
+// Behavioural contract = BGC_mod.F90:733-931 (clamps, zero-mask, quotas, light), 1041-1529 (kinetics), 1531-1536 ->
+// 2116-2699 (particles), 1545-1968 (tendencies, diagnostics, column integrals, O2 minimum), 2006-2109 (particle
+// initialisation).  The carbonate block 935-1032 is obgc_co2.h: a kernel of its own (obgc_carbonate.hip) or solved by the
+// lanes of the kernels here (FUSE).
 //
-// Arithmetic order is the reference's everywhere except three tendency sums that the hand-off
-// re-associates (Fe, SiO3, PO4: the per-autotroph terms are folded before the particle terms
-// are added) and P_iron production (Fe scavenging added last); the change is a few ulp of the
-// largest term, far inside the parity bar.
+// The reference walks each column sequentially, but only PAR, the particle fluxes, the QA-dust deficit and the column
+// integrals are really carried from level to level -- a few dozen flops per cell; the ~2 000 flops of kinetics per cell
+// are level-independent once PAR is known.  With one lane per column and level after level in registers the 100k-column
+// configuration offers 1 563 wavefronts for 1 024 SIMDs (measured: 5.2 ms, latency bound at one 512-register wave per
+// SIMD); both forms here give every cell a lane of its own for the kinetics.
+//
+// Arithmetic order is the reference's everywhere except three tendency sums that the hand-off re-associates (Fe, SiO3,
+// PO4: the per-autotroph terms are folded before the particle terms are added) and P_iron production (Fe scavenging added
+// last); the change is a few ulp of the largest term, far inside the parity bar.
 #include <cstdio>
 #include <cstring>
 
