@@ -162,7 +162,7 @@ class ColumnEngine:
         if dms_tracers is not None:
             ds = [E.dms.ind[i] - 1 for i in range(14)]
             for j, nm in enumerate(L.DMS_TRACERS[2:], start=2):
-                assert np.array_equal(dms_tracers[ds[j]], tracers[bslot[nm]]), "DMS tracer %s is not the BGC tracer" % nm
+                assert np.array_equal(dms_tracers[ds[j]], tracers[bslot[nm]], equal_nan=True), "DMS tracer %s is not the BGC tracer" % nm
             own.update(dms=up(dms_tracers[ds[0]], "kc"), dmsp=up(dms_tracers[ds[1]], "kc"), SST=up(sst, "c"),
                        dms_tend=up(np.full((nc, nz), diag_init), "kc"), dmsp_tend=up(np.full((nc, nz), diag_init), "kc"))
             if diagnostics:
@@ -170,7 +170,7 @@ class ColumnEngine:
         if macros_tracers is not None:
             ms = [E.macros.ind[i] - 1 for i in range(8)]
             for j, nm in enumerate(L.MACROS_TRACERS[3:], start=3):
-                assert np.array_equal(macros_tracers[ms[j]], tracers[bslot[nm]]), "MACROS tracer %s is not the BGC tracer" % nm
+                assert np.array_equal(macros_tracers[ms[j]], tracers[bslot[nm]], equal_nan=True), "MACROS tracer %s is not the BGC tracer" % nm
             own.update(prot=up(macros_tracers[ms[0]], "kc"), poly=up(macros_tracers[ms[1]], "kc"), lip=up(macros_tracers[ms[2]], "kc"),
                        prot_tend=up(np.full((nc, nz), diag_init), "kc"), poly_tend=up(np.full((nc, nz), diag_init), "kc"),
                        lip_tend=up(np.full((nc, nz), diag_init), "kc"))
