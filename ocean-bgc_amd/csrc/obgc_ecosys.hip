@@ -1248,6 +1248,9 @@ __device__ __forceinline__ void state_load(SweepState& S, double (*st)[64], int 
 // integrals are the exception in form only: their integrands go to four scratch planes and the column-integral kernel
 // sums them top to bottom, in the sweep kernel's order.
 // FUSE = 1: every lane goes on to solve the carbonate system of its cell (obgc_co2.h), as bgc_cell_kernel<.., 1> does.
+#ifndef OBGC_WALK_PRIO
+#define OBGC_WALK_PRIO 1
+#endif
 #ifdef OBGC_COLTIMING
 // Development build only (make BUILD=build_timing CXXEXTRA=-DOBGC_COLTIMING): shader-clock cycles per phase of the chunk
 // loop, summed over the wavefronts of a launch by wavefront index; printed by launch_bgc_column.
@@ -1320,6 +1323,9 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     // One wavefront walks the chunk's levels for the 64 columns -- a different one in every chunk, so that the four SIMDs
     // share the walk -- reading a cell's inputs from LDS and leaving its results in the same slots.
     if (w == (j & (kColLevels - 1)) && j * kColLevels < kmax) {
+#if OBGC_WALK_PRIO
+      __builtin_amdgcn_s_setprio(3);   // three wavefronts of this workgroup wait for this one
+#endif
       SweepState S;
       state_load(S, s_state, lane);
 #pragma unroll 1
@@ -1346,6 +1352,9 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
         }
       }
       state_store(S, s_state, lane);
+#if OBGC_WALK_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     OBGC_T(3);   // the walk (one wavefront per chunk)
     lds_barrier();   // the recurrence has passed the chunk
