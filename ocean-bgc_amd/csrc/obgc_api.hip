@@ -3,6 +3,8 @@
 // HIP kernels or returns a negative status.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -386,19 +388,26 @@ namespace {
 // bytes of engine scratch obgc_bgc_source_sink needs for the view the kernels run on
 // `column`: the column-block kernel keeps the light and the hand-off on the chip; only the chlorophyll profile of the 100 m
 // integral goes through memory
-size_t bgc_scratch_bytes(const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat, bool workspace_has_all, bool column = false) {
+// whether the column-block kernel solves the carbonate system in its own wavefronts (schedule 3) for this view
+bool column_fuses(const obgc_handle* h, const GridView& kv, bool have_diag) {
+  const bool large = (long long)kv.nlev * kv.ncol > 10000000LL;
+  return h->sched == 2 || (h->sched < 0 && large && have_diag);
+}
+
+size_t bgc_scratch_bytes(const obgc_handle* h, const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat, bool workspace_has_all,
+                         bool column = false) {
   const size_t kc1 = span_kc(kv, 1);
   size_t bytes = 0;
-  if (want_zsat) {
+  // (the column-block kernel with the carbonate solve inside searches the saturation horizons itself)
+  if (want_zsat && !(column && column_fuses(h, kv, diag != nullptr))) {
     if (!diag->CO3) bytes += align_up(kc1);
     if (!diag->co3_sat_calc) bytes += align_up(kc1);
     if (!diag->co3_sat_arag) bytes += align_up(kc1);
   }
   const long long span1 = (long long)(kc1 / sizeof(double));
   const long long splane = (span1 + 31) & ~31LL;
-  const int nslots = column ? (diag ? 5 : 0) : (diag ? (int)S_NDIAG : (int)S_NBASE);
+  const int nslots = column ? 0 : (diag ? (int)S_NDIAG : (int)S_NBASE);
   bytes += align_up((size_t)nslots * splane * sizeof(double));
-  if (column && diag) bytes += align_up((size_t)3 * kv.ncol * sizeof(double));
   if (diag) {
     const size_t zbytes = align_up((size_t)(3 * kv.plane + span1) * sizeof(double));
     const int nfb = (diag->photoC ? 0 : 1) + (diag->photoC_NO3 ? 0 : 1) + (diag->CaCO3_form ? 0 : 1) + (diag->bSi_form ? 0 : 1);
@@ -417,7 +426,7 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
     h->arena_used += align_up(bytes);
     return p;
   };
-  if (want_zsat) {
+  if (want_zsat && !(column && column_fuses(h, kv, K.have_diag != 0))) {
     K.co3_out = K.diag.CO3 ? K.diag.CO3 : carve(kc1);
     K.sat_calc_out = K.diag.co3_sat_calc ? K.diag.co3_sat_calc : carve(kc1);
     K.sat_arag_out = K.diag.co3_sat_arag ? K.diag.co3_sat_arag : carve(kc1);
@@ -426,9 +435,8 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
   const long long splane = (span1 + 31) & ~31LL;
   if (column) {
     K.scratch = nullptr;
-    K.chl100 = K.have_diag ? carve((size_t)5 * splane * sizeof(double)) : nullptr;
-    K.jw = K.have_diag ? K.chl100 + splane : nullptr;
-    K.jsed = K.have_diag ? carve((size_t)3 * kv.ncol * sizeof(double)) : nullptr;
+    K.chl100 = nullptr;
+    K.colint = K.have_diag;
   } else {
     const int nslots = K.have_diag ? (int)S_NDIAG : (int)S_NBASE;
     K.scratch = carve((size_t)nslots * splane * sizeof(double));
@@ -460,8 +468,7 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
 //     this form is one launch plus its column scans and leaves s_aux idle.
 // OBGC_SCHED = 0 forces schedule 4, 1 starts the carbonate kernel when the column kernel ends, 2 forces schedule 3.
 int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F) {
-  const bool large = (long long)K.g.nlev * K.g.ncol > 10000000LL;
-  const int fuse = (h->sched == 2 || (h->sched < 0 && large && K.have_diag)) ? 1 : 0;
+  const int fuse = column_fuses(h, K.g, K.have_diag != 0) ? 1 : 0;
   h->last_sched = fuse ? 3 : 4;
   FusedParams fp;
   fp.dms = h->dms;
@@ -475,7 +482,7 @@ int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, co
   HIP_TRY(h, hipEventRecord(h->ev_c0, h->s_aux));
   if (!fuse) launch_bgc_carbonate(K, h->bgc, h->s_aux);
   HIP_TRY(h, hipEventRecord(h->ev_c1, h->s_aux));
-  if (want_zsat) launch_bgc_zsat(K, h->s_aux);
+  if (want_zsat && !fuse) launch_bgc_zsat(K, h->s_aux);
   HIP_TRY(h, hipEventRecord(h->ev_aux_done, h->s_aux));
   HIP_TRY(h, hipStreamWaitEvent(h->s_aux2, h->ev_k1, 0));   // zint reads the column kernel's profiles
   launch_bgc_zint(K, h->bgc, h->s_aux2);
@@ -486,7 +493,14 @@ int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, co
   return OBGC_OK;
 }
 
+// every launch set starts here or in bgc_launch_hybrid: the scratch it was given must lie inside the reserved arena
+inline int arena_check(obgc_handle* h) {
+  if (h->arena_used > h->arena_bytes) return fail(h, OBGC_ERR_INVALID, "internal: scratch carved beyond the reserved arena");
+  return OBGC_OK;
+}
+
 int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F = nullptr) {
+  if (int rc = arena_check(h)) return rc;
   // the scratch was carved for one form or the other (bgc_carve_scratch): the column-block kernel has no hand-off planes
   if (!K.g.kfast && K.scratch == nullptr) return bgc_launch_column(h, K, want_zsat, F);
   if (K.scratch == nullptr) return fail(h, OBGC_ERR_INVALID, "internal: the separate kernels were launched without their hand-off planes");
@@ -532,6 +546,7 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const Fus
 //   W : a dense column-fastest workspace view of one tile (own scratch), filled/drained here
 int bgc_launch_hybrid(obgc_handle* h, const BgcKernelArgs& K, BgcKernelArgs W, bool want_zsat, int tile, int c_begin = 0,
                       int c_end = -1) {
+  if (int rc = arena_check(h)) return rc;
   const GridView& v = K.g;
   const obgc_bgc_params& P = h->bgc;
   const long long wl = W.g.sk;
@@ -835,10 +850,12 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   obgc_bgc_diag wdiag0;                   // hybrid: the workspace owns every level-dependent plane it uses
   std::memset(&wdiag0, 0, sizeof wdiag0);
   const bool column = !tiled && !v.kfast && h->column;   // generic strides (OBGC_KFAST_DIRECT=1) keep the separate kernels
-  size_t scratch = bgc_scratch_bytes(kv, a->diag, want_zsat, tiled, column);
+  size_t scratch = bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, column);
+  // the tile workspace runs whichever kernel form the handle selects: reserve for the larger of the two
+  if (tiled && !hybrid) scratch = std::max(scratch, bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, h->column != 0));
   if (hybrid) {
     work = align_up(tplane * (size_t)(30 + 5 + 30 + 27));
-    scratch = bgc_scratch_bytes(v, a->diag, want_zsat, false) + bgc_scratch_bytes(kv, a->diag ? &wdiag0 : nullptr, want_zsat, true);
+    scratch = bgc_scratch_bytes(h, v, a->diag, want_zsat, false) + bgc_scratch_bytes(h, kv, a->diag ? &wdiag0 : nullptr, want_zsat, true);
   }
   int rc = arena_reserve(h, (st.host ? st.need : 0) + work + scratch);
   if (rc != OBGC_OK) return rc;
@@ -995,7 +1012,7 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   // (the column-block kernel needs none of it: DMS's light runs through LDS beside BGC's)
   const size_t dms_scratch = (a->dms && !h->column) ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
   const bool column = h->column != 0;
-  int rc = arena_reserve(h, bgc_scratch_bytes(v, b.diag, want_zsat, false, column) + dms_scratch);
+  int rc = arena_reserve(h, bgc_scratch_bytes(h, v, b.diag, want_zsat, false, column) + dms_scratch);
   if (rc != OBGC_OK) return rc;
 
   BgcKernelArgs K;

@@ -384,7 +384,10 @@ __device__ __forceinline__ void carbonate_load(const BgcKernelArgs& A, int i_dic
   }
 }
 
-__device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool inside, int k, const CarbIn& in);
+// what the saturation-horizon search (BGC_mod.F90:1003-1032) needs from a cell's carbonate block
+struct CarbOut { double CO3, sat_calc, sat_arag; };
+
+__device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool inside, int k, const CarbIn& in, CarbOut* out = nullptr);
 
 __device__ __forceinline__ void carbonate_cell(const BgcKernelArgs& A, int i_dic, int i_alk, int i_po4, int i_sio3, bool inside,
                                                int k, int c) {
@@ -393,7 +396,7 @@ __device__ __forceinline__ void carbonate_cell(const BgcKernelArgs& A, int i_dic
   carbonate_solve(A, inside, k, in);
 }
 
-__device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool inside, int k, const CarbIn& in) {
+__device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool inside, int k, const CarbIn& in, CarbOut* out) {
   const bool live = in.live;
   const long long ix = in.ix;
   double T = 10.0, S = 35.0, depth = 0.0, dic = 2000.0, alk = 2300.0, po4 = 0.0, sio3 = 0.0;
@@ -469,6 +472,7 @@ __device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool ins
     const double H2CO3 = (dic_m * hh * denom) * OBGC_MASS_TO_VOL;
     const double HCO3 = (dic_m * cc.k1 * h1 * denom) * OBGC_MASS_TO_VOL;
     const double CO3 = (dic_m * cc.k1 * cc.k2 * denom) * OBGC_MASS_TO_VOL;
+    if (out) { out->CO3 = CO3; out->sat_calc = sat_calc; out->sat_arag = sat_arag; }
     if (A.co3_out) A.co3_out[ix] = CO3;
     if (A.sat_calc_out) A.sat_calc_out[ix] = sat_calc;
     if (A.sat_arag_out) A.sat_arag_out[ix] = sat_arag;

@@ -273,6 +273,7 @@ struct LevelIn {
   double prodPOC, prodCa, prodSi, PfeLoc;
   double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_alk, L_o2;
   double oc0, d0, jc, jn, jp, jsi;   // DIAG only
+  double chl100;                     // DIAG, column-block kernel only: chlorophyll x thickness above 100 m
 };
 
 // Dissolution length scales and decay factors across one level (2273-2339): cell-local functions of zbot, T, O2 and dz.
@@ -873,7 +874,8 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     const double j_c = t_doc + t_zooC + sC + sCa, j_n = t_don + QN * t_zooC + QN * sC - sNfix, j_p = t_dop + QP_ZOO_POM * t_zooC + sQpC;
     if (COLK) { lo->oc0 = OC0; lo->d0 = D0; lo->jc = j_c; lo->jn = j_n; lo->jp = j_p; lo->jsi = sSi; }
     else { SCR(S_OC0) = OC0; SCR(S_D0) = D0; SCR(S_JC) = j_c; SCR(S_JN) = j_n; SCR(S_JP) = j_p; SCR(S_JSI) = sSi; }
-    A.chl100[ix] = chl * pt100;
+    if (COLK) lo->chl100 = chl * pt100;
+    else A.chl100[ix] = chl * pt100;
   }
   return true;
 #undef RAW
@@ -1231,6 +1233,97 @@ __device__ __forceinline__ void state_load(SweepState& S, double (*st)[64], int 
   S.zbot_above = 0.0;
 }
 
+// ---- column integrals inside the column-block kernel (diagnostics only) ----
+// The conservation integrals (BGC_mod.F90:1870-1938), the O2 minimum (1954-1968), chlorophyll over the top 100 m
+// (1940-1945) and -- when the carbonate system is solved inside the kernel -- the saturation horizons (1003-1032) are
+// top-to-bottom sums and searches over quantities that are final only when a cell's finishing arithmetic is.  Once a lane
+// has read its own entries of the hand-off slots in the finish phase, those entries are dead until the next chunk's cell
+// terms: the lane leaves its integrands there, and after ONE more LDS barrier per chunk four wavefronts each take one
+// kind of integral for the 64 columns over the chunk's levels, in the reference's order (same bits as the column-integral
+// kernel).  Running values rest in LDS between chunks.  The barrier stands behind the next chunk's loads, which are in
+// flight while the integrals advance.
+enum IntegrandSlot {   // own entries of the hand-off slots; the burial fluxes are read where the walk left them (H_OUT_SED*)
+  I_SATC = 0, I_SATA = 1,
+  I_JC = H_NIN, I_JN, I_JP, I_JSI, I_DZ, I_ZB, I_O2, I_ZMID, I_CHL, I_CO3,
+  I_END
+};
+static_assert((int)I_END <= (int)H_NSLOTS && (int)I_SATA < (int)H_OUT_SEDPOC, "integrands must not touch the burial fluxes of the walk");
+enum IntegralState {
+  N_J0, N_J1, N_J2, N_J3, N_J4, N_J5, N_J6, N_J7,   // C, C 100 m, N, N 100 m, P, P 100 m, Si, Si 100 m
+  N_ZABOVE0, N_ZABOVE1,                              // bottom depth of the level above, one copy per integrating wavefront
+  N_ZC, N_ZA, N_ANOMC, N_ANOMA, N_ZPREV,             // saturation horizons: results, anomalies and depth of the level above
+  N_O2MIN, N_O2Z, N_CHL,
+  N_INTEGRALS
+};
+
+// one kind of integral (role = wavefront index) for column `lane` over the levels of chunk j
+template <int FUSE>
+__device__ __forceinline__ void integrate_chunk(double (*ho)[kColThreads], double (*st)[64], int role, int lane, int kmax, int j) {
+  const int k0 = j * kColLevels;
+  if (k0 >= kmax) return;
+  if (role < 2) {
+    // role 0: carbon and nitrogen, role 1: phosphorus and silicon (accumulate_J: the other half is dead code)
+    double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (role == 0) { J[0] = st[N_J0][lane]; J[1] = st[N_J1][lane]; J[2] = st[N_J2][lane]; J[3] = st[N_J3][lane]; }
+    else { J[4] = st[N_J4][lane]; J[5] = st[N_J5][lane]; J[6] = st[N_J6][lane]; J[7] = st[N_J7][lane]; }
+    double zabove = role == 0 ? st[N_ZABOVE0][lane] : st[N_ZABOVE1][lane];
+#pragma unroll 1
+    for (int l = 0; l < kColLevels; ++l) {
+      if (k0 + l >= kmax) break;
+      const int t = l * 64 + lane;
+      JTerms jt{0.0, 0.0, 0.0, 0.0};
+      double sedCa = 0.0, sedSi = 0.0;
+      if (role == 0) { jt.C = ho[I_JC][t]; jt.N = ho[I_JN][t]; sedCa = ho[H_OUT_SEDCA][t]; }
+      else { jt.P = ho[I_JP][t]; jt.Si = ho[I_JSI][t]; sedSi = ho[H_OUT_SEDSI][t]; }
+      const double zb = ho[I_ZB][t];
+      accumulate_J(J, jt, ho[I_DZ][t], zb, zabove, ho[H_OUT_SEDPOC][t], sedCa, sedSi);
+      zabove = zb;
+    }
+    if (role == 0) { st[N_J0][lane] = J[0]; st[N_J1][lane] = J[1]; st[N_J2][lane] = J[2]; st[N_J3][lane] = J[3]; st[N_ZABOVE0][lane] = zabove; }
+    else { st[N_J4][lane] = J[4]; st[N_J5][lane] = J[5]; st[N_J6][lane] = J[6]; st[N_J7][lane] = J[7]; st[N_ZABOVE1][lane] = zabove; }
+  } else if (role == 2) {
+    if (FUSE) {   // saturation horizons: first crossing down the column (BGC_mod.F90:1003-1032)
+      double zc = st[N_ZC][lane], za = st[N_ZA][lane], anom_c = st[N_ANOMC][lane], anom_a = st[N_ANOMA][lane], zprev = st[N_ZPREV][lane];
+#pragma unroll 1
+      for (int l = 0; l < kColLevels; ++l) {
+        const int k = k0 + l;
+        if (k >= kmax) break;
+        const int t = l * 64 + lane;
+        const double CO3 = ho[I_CO3][t], sc = ho[I_SATC][t], sa = ho[I_SATA][t], zmid = ho[I_ZMID][t];
+        if (k == 0) {
+          zc = (CO3 > sc) ? -1.0 : 0.0;
+          za = (CO3 > sa) ? -1.0 : 0.0;
+        } else {
+          const double w4 = zprev + (zmid - zprev);                       // BGC_mod.F90:1009
+          if (zc == -1.0 && CO3 <= sc) zc = w4 * anom_c / (anom_c - (CO3 - sc));
+          if (za == -1.0 && CO3 <= sa) za = w4 * anom_a / (anom_a - (CO3 - sa));
+          if (k == kmax - 1) {
+            const double zb = ho[I_ZB][t];
+            if (zc == -1.0) zc = zb;
+            if (za == -1.0) za = zb;
+          }
+        }
+        anom_c = CO3 - sc;
+        anom_a = CO3 - sa;
+        zprev = zmid;
+      }
+      st[N_ZC][lane] = zc; st[N_ZA][lane] = za; st[N_ANOMC][lane] = anom_c; st[N_ANOMA][lane] = anom_a; st[N_ZPREV][lane] = zprev;
+    }
+  } else {
+    double o2min = st[N_O2MIN][lane], o2min_z = st[N_O2Z][lane], chl = st[N_CHL][lane];
+#pragma unroll 1
+    for (int l = 0; l < kColLevels; ++l) {
+      const int k = k0 + l;
+      if (k >= kmax) break;
+      const int t = l * 64 + lane;
+      const double O2 = ho[I_O2][t];
+      if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = ho[I_ZMID][t]; }   // 1954-1968
+      chl = chl + ho[I_CHL][t];                                             // 1940-1945
+    }
+    st[N_O2MIN][lane] = o2min; st[N_O2Z][lane] = o2min_z; st[N_CHL][lane] = chl;
+  }
+}
+
 // ------------------------------------------------------------------------- column-block kernel
 // The whole ecosystem part of BGC_SourceSink (and, for obgc_fused_step, DMS_SourceSink and MACROS_SourceSink) in ONE
 // launch for callers in the native layout.  A workgroup owns 64 adjacent columns and marches down them in chunks of
@@ -1243,10 +1336,11 @@ __device__ __forceinline__ void state_load(SweepState& S, double (*st)[64], int 
 //     levels (state of the 64 columns in LDS between chunks) and leaves its results in the same slots; every lane then
 //     finishes its own cell: the particle-dependent part of 11 tendencies and 27 diagnostics (no hand-off planes, no
 //     tendency written twice, no second read of dz, zbot, T, O2, NO3, Fe by a sweep kernel).
-// Three barriers per chunk: attenuations in LDS, recurrence inputs in LDS, recurrence results in LDS.  Same statements in
-// the same order as the separate kernels, hence the same bits (tests/test_gpu_column_kernel.py).  The conservation
-// integrals are the exception in form only: their integrands go to four scratch planes and the column-integral kernel
-// sums them top to bottom, in the sweep kernel's order.
+// Three barriers per chunk: attenuations in LDS, recurrence inputs in LDS, recurrence results in LDS (a fourth with
+// diagnostics, for the column integrals: integrate_chunk above).  Same statements in the same order as the separate
+// kernels, hence the same bits (tests/test_gpu_column_kernel.py).  Only the vertical integrals of the production
+// profiles are left to the column-integral kernel: their ~12 integrands per cell are known before the walk and there is
+// neither LDS nor register room to keep them until a wavefront is free to sum them.
 // FUSE = 1: every lane goes on to solve the carbonate system of its cell (obgc_co2.h), as bgc_cell_kernel<.., 1> does.
 #ifndef OBGC_WALK_PRIO
 #define OBGC_WALK_PRIO 1
@@ -1269,6 +1363,7 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
   // The recurrence state of the 64 columns rests in LDS between chunks: whichever wavefront walks a chunk holds it in
   // registers only while it does, so the cell terms do not share the register file with it.
   __shared__ double s_state[kStateVals][64];
+  __shared__ double s_int[DIAG ? (int)N_INTEGRALS : 1][64];   // running column integrals (integrate_chunk)
   const GridView& g = A.g;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -1285,6 +1380,10 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     s_par[0][lane] = sw * F_QSW_PAR;
     if (DM) s_pard[0][lane] = sw * F.f_qsw_par_dms;
   }
+  if (DIAG) {   // first read behind the integrals' barrier of the second chunk
+    for (int i = w; i < (int)N_INTEGRALS; i += kColLevels) s_int[i][lane] = 0.0;
+  }
+  const int role = __builtin_amdgcn_readfirstlane(w);   // which integrals this wavefront advances
   const int nchunk = (g.nlev + kColLevels - 1) / kColLevels;
 #ifdef OBGC_COLTIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tnow, tlast = __builtin_readcyclecounter();
@@ -1312,6 +1411,10 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     // boundary cost more in spills than the wait, 44.9 ms against 41.3 ms at 1 M columns x 80 levels.)
     CellIn in;
     cell_load<DIAG, DM, true>(*Ap, *Pp, DM ? Fp : nullptr, kc, cc, in);
+    if (DIAG && j > 0) {   // the chunk above has left its integrands in the slots; this chunk's loads are in flight
+      lds_barrier();
+      integrate_chunk<FUSE>(s_ho, s_int, role, lane, kmax, j - 1);
+    }
 #ifdef OBGC_COLTIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     OBGC_T(0);   // the chunk's loads (behind the stores of the chunk before)
@@ -1363,6 +1466,9 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     // operations complete in issue order, so requested behind them they would wait for every one of them.
     CarbIn cin;
     if (FUSE) carbonate_load(*Ap, Pp->ind[6], Pp->ind[8], Pp->ind[0], Pp->ind[2], X.valid, X.k, X.valid ? c : 0, cin);
+    double zmid_i = 0.0;   // depth of the cell centre, for the O2 minimum and the saturation horizons
+    if (DIAG && !FUSE && active) zmid_i = Ap->zmid[g.at(X.k, c)];
+    JTerms jt{0.0, 0.0, 0.0, 0.0};
     if (active) {
       const int t = threadIdx.x;
       const long long ix = g.at(X.k, c);
@@ -1379,22 +1485,34 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
       lo.L_no3 = s_ho[H_L_NO3][t]; lo.L_nh4 = s_ho[H_L_NH4][t]; lo.L_fe = s_ho[H_L_FE][t]; lo.L_sio3 = s_ho[H_L_SIO3][t];
       lo.L_po4 = s_ho[H_L_PO4][t]; lo.L_donr = s_ho[H_L_DONR][t]; lo.L_dopr = s_ho[H_L_DOPR][t]; lo.L_dic = s_ho[H_L_DIC][t];
       lo.L_alk = s_ho[H_L_ALK][t]; lo.L_o2 = s_ho[H_L_O2][t];
-      const JTerms jt = sweep_finish<DIAG>(*Ap, *Pp, ix, lo, o, X.k < kmax);
-      if (DIAG) {
-        // integrands of the conservation integrals: summed top to bottom by the column-integral kernel
-        double* jw = Ap->jw;
-        const long long sp = Ap->splane;
-        jw[ix] = jt.C; jw[sp + ix] = jt.N; jw[2 * sp + ix] = jt.P; jw[3 * sp + ix] = jt.Si;
-        if (X.k == kmax - 1) {
-          double* js = Ap->jsed;
-          js[c] = o.sedPOC; js[g.ncol + c] = o.sedCa; js[2LL * g.ncol + c] = o.sedSi;
-        }
-      }
+      jt = sweep_finish<DIAG>(*Ap, *Pp, ix, lo, o, X.k < kmax);
     }
     OBGC_T(5);   // finish
     // no barrier here: the next chunk's first write into the slots sits behind its light barrier
-    if (FUSE) carbonate_solve(*Ap, X.valid, X.k, cin);
+    CarbOut co{0.0, 0.0, 0.0};
+    if (FUSE) carbonate_solve(*Ap, X.valid, X.k, cin, DIAG ? &co : nullptr);
+    if (DIAG && active && X.k < kmax) {
+      // integrands of the column integrals, into this lane's own (now dead) entries of the hand-off slots
+      const int t = threadIdx.x;
+      s_ho[I_JC][t] = jt.C; s_ho[I_JN][t] = jt.N; s_ho[I_JP][t] = jt.P; s_ho[I_JSI][t] = jt.Si;
+      s_ho[I_DZ][t] = lo.dz; s_ho[I_ZB][t] = lo.zb; s_ho[I_O2][t] = lo.O2; s_ho[I_CHL][t] = lo.chl100;
+      s_ho[I_ZMID][t] = FUSE ? cin.zmid : zmid_i;
+      if (FUSE) { s_ho[I_CO3][t] = co.CO3; s_ho[I_SATC][t] = co.sat_calc; s_ho[I_SATA][t] = co.sat_arag; }
+    }
     OBGC_T(6);
+  }
+  if (DIAG) {
+    lds_barrier();
+    integrate_chunk<FUSE>(s_ho, s_int, role, lane, kmax, nchunk - 1);
+    if (colvalid) {   // each wavefront stores the integrals it advanced (its own LDS entries: no barrier)
+      const obgc_bgc_diag& D = A.diag;
+#define ST_C(name, n) do { if (D.name) D.name[c] = s_int[n][lane]; } while (0)
+      if (role == 0) { ST_C(Jint_Ctot, N_J0); ST_C(Jint_100m_Ctot, N_J1); ST_C(Jint_Ntot, N_J2); ST_C(Jint_100m_Ntot, N_J3); }
+      else if (role == 1) { ST_C(Jint_Ptot, N_J4); ST_C(Jint_100m_Ptot, N_J5); ST_C(Jint_Sitot, N_J6); ST_C(Jint_100m_Sitot, N_J7); }
+      else if (role == 2) { if (FUSE) { ST_C(zsatcalc, N_ZC); ST_C(zsatarag, N_ZA); } }
+      else { ST_C(O2_ZMIN, N_O2MIN); ST_C(O2_ZMIN_DEPTH, N_O2Z); ST_C(Chl_TOT_zint_100m, N_CHL); }
+#undef ST_C
+    }
   }
 #ifdef OBGC_COLTIMING
   if (lane == 0)
@@ -1403,9 +1521,10 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
 }
 
 // ---------------------------------------------------------------- column integrals (diagnostics only)
-// Vertical integrals of the production profiles, chlorophyll over the top 100 m and the O2 minimum
-// (BGC_mod.F90:1230, 1273-1277, 1816-1846, 1940-1945, 1954-1968).  None of them feeds or needs the particle
-// recurrence, so they run beside the sweep on another stream.  Sums keep the reference's top-down order.
+// Vertical integrals of the production profiles (BGC_mod.F90:1230, 1273-1277, 1816-1846) and, for the separate kernels,
+// chlorophyll over the top 100 m and the O2 minimum (1940-1945, 1954-1968), which the column-block kernel advances itself
+// (A.colint).  None of them feeds or needs the particle recurrence.  Sums keep the reference's top-down order.
+template <bool COLINT>
 __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
   const GridView& g = A.g;
   const int c = blockIdx.x * kBlockCol + threadIdx.x;
@@ -1419,18 +1538,16 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
   double z_Ca[4] = {0, 0, 0, 0}, z_pC[4] = {0, 0, 0, 0}, z_pCNO3[4] = {0, 0, 0, 0};
   double o2min = 0.0, o2min_z = 0.0;
   const double* chl100 = A.chl100;
-  // column-block kernel only: the conservation integrals from the integrands its cells left (jw), in the sweep's order
-  const bool do_j = A.jw != nullptr;
-  double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  double zbot_above = 0.0;
   const double* o2p = A.tracers + (long long)(P.ind[5] - 1) * pl;
-  // not unrolled: 154 registers and three wavefronts per SIMD instead of 228 and two (2.68 against 2.80 ms at 1 M x 80)
+  // not unrolled: three wavefronts per SIMD instead of two (2.68 against 2.80 ms at 1 M x 80)
 #pragma unroll 1
   for (int k = 0; k < kmax; ++k) {
     const long long ix = g.at(k, c);
     const double dz = A.dz[ix];
-    const double O2 = dmax(0.0, o2p[ix]);
-    if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = A.zmid[ix]; }
+    if (!COLINT) {
+      const double O2 = dmax(0.0, o2p[ix]);
+      if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = A.zmid[ix]; }
+    }
     double pC[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -1449,33 +1566,17 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
       z_pCNO3[a] = z_pCNO3[a] + A.z_photoC_NO3[(long long)a * pl + ix] * dz;
       z_pCNO3Tot = z_pCNO3Tot + z_pCNO3[a];   // adds the RUNNING integral (1844-1846)
     }
-    z_Chl100 = z_Chl100 + chl100[ix];
-    if (do_j) {
-      const JTerms jt{A.jw[ix], A.jw[A.splane + ix], A.jw[2 * A.splane + ix], A.jw[3 * A.splane + ix]};
-      const double zb = A.zbot[ix];
-      const bool bottom = k == kmax - 1;
-      accumulate_J(J, jt, dz, zb, zbot_above, bottom ? A.jsed[c] : 0.0, bottom ? A.jsed[g.ncol + c] : 0.0,
-                   bottom ? A.jsed[2LL * g.ncol + c] : 0.0);
-      zbot_above = zb;
-    }
+    if (!COLINT) z_Chl100 = z_Chl100 + chl100[ix];
   }
-  if (do_j) {
-    if (D.Jint_Ctot) D.Jint_Ctot[c] = J[0];
-    if (D.Jint_100m_Ctot) D.Jint_100m_Ctot[c] = J[1];
-    if (D.Jint_Ntot) D.Jint_Ntot[c] = J[2];
-    if (D.Jint_100m_Ntot) D.Jint_100m_Ntot[c] = J[3];
-    if (D.Jint_Ptot) D.Jint_Ptot[c] = J[4];
-    if (D.Jint_100m_Ptot) D.Jint_100m_Ptot[c] = J[5];
-    if (D.Jint_Sitot) D.Jint_Sitot[c] = J[6];
-    if (D.Jint_100m_Sitot) D.Jint_100m_Sitot[c] = J[7];
+  if (!COLINT) {
+    if (D.O2_ZMIN) D.O2_ZMIN[c] = o2min;
+    if (D.O2_ZMIN_DEPTH) D.O2_ZMIN_DEPTH[c] = o2min_z;
+    if (D.Chl_TOT_zint_100m) D.Chl_TOT_zint_100m[c] = z_Chl100;
   }
-  if (D.O2_ZMIN) D.O2_ZMIN[c] = o2min;
-  if (D.O2_ZMIN_DEPTH) D.O2_ZMIN_DEPTH[c] = o2min_z;
   if (D.tot_bSi_form) D.tot_bSi_form[c] = z_bSi;
   if (D.tot_CaCO3_form_zint) D.tot_CaCO3_form_zint[c] = z_CaTot;
   if (D.photoC_TOT_zint) D.photoC_TOT_zint[c] = z_pCTot;
   if (D.photoC_NO3_TOT_zint) D.photoC_NO3_TOT_zint[c] = z_pCNO3Tot;
-  if (D.Chl_TOT_zint_100m) D.Chl_TOT_zint_100m[c] = z_Chl100;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     if (D.CaCO3_form_zint) D.CaCO3_form_zint[(long long)a * g.ldc + c] = z_Ca[a];
@@ -1579,7 +1680,8 @@ void launch_bgc_column(const BgcKernelArgs& a, const obgc_bgc_params& p, const F
 void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
   if (a.g.ncol <= 0 || !a.have_diag) return;
   const unsigned gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
-  hipLaunchKernelGGL(bgc_zint_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+  if (a.colint) hipLaunchKernelGGL(bgc_zint_kernel<true>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+  else hipLaunchKernelGGL(bgc_zint_kernel<false>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
 }
 
 template <int LANES>

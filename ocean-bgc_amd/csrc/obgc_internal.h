@@ -72,10 +72,11 @@ struct BgcKernelArgs {
   // integrates vertically: the caller's diagnostic arrays when given, else scratch (4 planes each)
   double* scratch;
   long long splane;
-  double* chl100;   // diagnostics only: chlorophyll x thickness above 100 m of every cell, summed by the column-integral kernel
-  // column-block kernel with diagnostics: integrands of the four conservation integrals (4 planes, stride splane) and the
-  // three burial fluxes of each column's bottom cell (3 vectors, stride ncol); NULL otherwise (the sweep kernel sums them)
-  double *jw, *jsed;
+  // separate kernels with diagnostics: chlorophyll x thickness above 100 m of every cell, summed by the column-integral kernel
+  double* chl100;
+  // the column-block kernel advances the conservation integrals, the O2 minimum and the 100 m chlorophyll integral itself
+  // (and the saturation horizons when it solves the carbonate system): the column-integral kernel skips them
+  int colint;
   double *z_photoC, *z_photoC_NO3, *z_CaCO3_form, *z_bSi_form;
   obgc_bgc_diag diag;
   int have_diag;

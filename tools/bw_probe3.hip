@@ -1,0 +1,83 @@
+// Streaming probe for the column-block kernel's access pattern, to compare OUTPUT (and input) layouts without the
+// arithmetic.  A workgroup of 256 lanes owns 64 adjacent columns and marches down them in chunks of 4 levels (wavefront =
+// level, lane = column), as bgc_column_kernel does; every cell reads NIN values and writes NOUT values, 8 bytes each.
+// 70 KB of LDS per workgroup hold the occupancy at the column kernel's two workgroups per CU.
+//
+//   layout 0  plane-major (the native layout):       X[plane][level][column]
+//   layout 1  level-major tiles:                     X[level][block][plane][64]      block = 64 adjacent columns
+//   layout 2  column-block-major tiles:              X[block][level][plane][64]      a workgroup's whole output is one run
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/bw_probe3.hip -o gpurun_out/bw_probe3 && gpurun_out/bw_probe3 [ncol] [nlev]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int LAYOUT>
+__device__ __forceinline__ long long addr(int p, int k, int b, int lane, int np, int nlev, long long nblk) {
+  if (LAYOUT == 0) return ((long long)p * nlev + k) * (nblk * 64) + (long long)b * 64 + lane;
+  if (LAYOUT == 1) return (((long long)k * nblk + b) * np + p) * 64 + lane;
+  return (((long long)b * nlev + k) * np + p) * 64 + lane;
+}
+
+template <int NIN, int NOUT, int LIN, int LOUT, int WORK>
+__global__ __launch_bounds__(256, 2) void probe(const double* __restrict__ in, double* __restrict__ out, int nlev, long long nblk) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  for (int k = w; k < nlev; k += 4) {
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < NIN; ++p) acc += in[addr<LIN>(p, k, b, lane, NIN, nlev, nblk)];
+    if (acc == 12345.678) lds[threadIdx.x] = acc;   // keeps the LDS allocation alive
+#pragma unroll
+    for (int p = 0; p < NOUT; ++p) {
+      double v = acc + p;
+#pragma unroll
+      for (int i = 0; i < WORK; ++i) v = v * 1.0000001 + 0.5;   // dependent fp64 work between the stores
+      out[addr<LOUT>(p, k, b, lane, NOUT, nlev, nblk)] = v;
+    }
+  }
+}
+
+template <int NIN, int NOUT, int LIN, int LOUT, int WORK>
+void run(const double* in, double* out, int ncol, int nlev) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const long long nblk = ncol / 64;
+  const size_t shm = 70 * 1024;
+  CK(hipFuncSetAttribute((const void*)probe<NIN, NOUT, LIN, LOUT, WORK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int r = 0; r < 2; ++r) probe<NIN, NOUT, LIN, LOUT, WORK><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
+  CK(hipEventRecord(a));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) probe<NIN, NOUT, LIN, LOUT, WORK><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+  const double bytes = 8.0 * nblk * 64 * nlev * (NIN + NOUT);
+  printf("in %3d (layout %d) out %3d (layout %d) work %d : %8.3f ms  %6.2f TB/s\n", NIN, LIN, NOUT, LOUT, WORK, ms, bytes / ms * 1e-9);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const int ncol = (argc > 1) ? atoi(argv[1]) : 320000;   // a multiple of 64
+  const int nlev = (argc > 2) ? atoi(argv[2]) : 80;
+  const long long n = (long long)ncol * nlev;
+  double *in, *out;
+  CK(hipMalloc(&in, 8 * n * 48)); CK(hipMalloc(&out, 8 * n * 200));
+  CK(hipMemset(in, 0, 8 * n * 48)); CK(hipMemset(out, 0, 8 * n * 200));
+  printf("%d columns x %d levels, %.1f GB\n", ncol, nlev, 8.0 * n * 248 * 1e-9);
+  run<43, 200, 0, 0, 0>(in, out, ncol, nlev);
+  run<43, 200, 0, 1, 0>(in, out, ncol, nlev);
+  run<43, 200, 0, 2, 0>(in, out, ncol, nlev);
+  run<43, 200, 1, 1, 0>(in, out, ncol, nlev);
+  run<43, 200, 2, 2, 0>(in, out, ncol, nlev);
+  run<43, 200, 0, 0, 4>(in, out, ncol, nlev);
+  run<43, 200, 0, 2, 4>(in, out, ncol, nlev);
+  run<43, 200, 2, 2, 4>(in, out, ncol, nlev);
+  run<43, 37, 0, 0, 0>(in, out, ncol, nlev);    // tendencies only
+  run<43, 37, 2, 2, 0>(in, out, ncol, nlev);
+  run<0, 200, 0, 0, 0>(in, out, ncol, nlev);    // writes only
+  run<0, 200, 0, 2, 0>(in, out, ncol, nlev);
+  run<43, 0, 0, 0, 0>(in, out, ncol, nlev);     // (the sum is never stored: the reads may be elided)
+  return 0;
+}
