@@ -185,29 +185,57 @@ def cpu_baseline(nz, modules, seconds_per_worker=3.0):   # measured: ~1.35 us / 
 class Workload:
     """Device-resident inputs and outputs of one configuration, generated on the device (bit-identical to synth.py)."""
 
-    def __init__(self, eng, torch, L, name, ncol, nz, modules, col0, diag_on, ph, steps, fused):
+    def __init__(self, eng, torch, L, name, ncol, nz, modules, col0, diag_on, ph, steps, fused, layout="tiled"):
         self.eng, self.torch, self.L = eng, torch, L
         self.name, self.ncol, self.nz, self.modules, self.diag_on, self.ph = name, ncol, nz, modules, diag_on, ph
         dev = torch.device("cuda", torch.cuda.current_device())
         f64 = dict(dtype=torch.float64, device=dev)
         E = torch.empty
-        self.tr = E((30, nz, ncol), **f64)
-        self.kc = {nm: E((nz, ncol), **f64) for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesedflux")}
+        self.fused = bool(fused) and ("dms" in modules and "macros" in modules) and hasattr(eng, "fused_step")
+        # the separate DMS / MACROS entry points keep scratch in the caller's index space: native layout only
+        self.tiled = layout == "tiled" and (self.fused or not ("dms" in modules or "macros" in modules))
+        self.nbuf = 1 if ph == "warm" else max(1, min(steps, 8))
+        with_own = "dms" in modules or "macros" in modules or "dms_surf" in modules
+        with_dtr = ("dms" in modules or "dms_surf" in modules) and (not self.fused or "dms_surf" in modules)
+        if self.tiled:
+            # ONE arena for every level-dependent array: arena[block of 64 columns][level][row][64]; inputs first
+            from ocean_bgc_amd.engine import TileArena
+            nrows = 30 + 6 + (5 if with_own else 0) + (14 if with_dtr else 0) + 30 + 2 * self.nbuf
+            if with_own:
+                nrows += 5
+            if diag_on:
+                nrows += len(L.BGC_DIAG_KC) - len(L.BGC_DIAG_KC_UNTOUCHED) + 4 * len(L.BGC_DIAG_KCA)
+                nrows += (len(L.DMS_DIAG_KC) if "dms" in modules else 0) + (len(L.MACROS_DIAG_KC) if "macros" in modules else 0)
+            self.arena = TileArena(torch, dev, ncol, nz, nrows)
+            KC = lambda n=1: self.arena.take(n, (ncol, nz) if n == 1 else None)
+            self.gkw = dict(ld=self.arena.ld, plane=64)
+            self.layout = L.OBGC_LAYOUT_TILED
+            plane_of = lambda x, j: x.sub(j)
+            view_of = lambda x, j: x.view()[:, :, j, :]
+        else:
+            KC = lambda n=1: E((nz, ncol) if n == 1 else (n, nz, ncol), **f64)
+            self.gkw = {}
+            self.layout = L.OBGC_LAYOUT_COLFAST
+            plane_of = lambda x, j: x[j]
+            view_of = plane_of
+        self.tr = KC(30)
+        self.kc = {nm: KC() for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesedflux")}
         self.cc = {nm: E((ncol,), **f64) for nm in ("lat", "dust_flux_in", "sw_flux")}
         self.kmax = E((ncol,), dtype=torch.int32, device=dev)
-        eng.synth_fill(nz, ncol, col0, tracers=self.tr, kmax=self.kmax, **self.kc, **self.cc)
-        self.tend = E((30, nz, ncol), **f64)
+        eng.synth_fill(nz, ncol, col0, tracers=self.tr, kmax=self.kmax, tiled=self.tiled, **self.gkw, **self.kc, **self.cc)
+        own = KC(5) if with_own else None
+        dtr = KC(14) if with_dtr else None
+        self.tend = KC(30)
         # cold start per step: a zeroed pH state pair per step, rotated over at most 8 buffers
-        self.nbuf = 1 if ph == "warm" else max(1, min(steps, 8))
-        self.phs = [torch.zeros((2, nz, ncol), **f64) for _ in range(self.nbuf)]
+        self.phs = [(KC().zero_(), KC().zero_()) for _ in range(self.nbuf)]
         self.diag = None
         if diag_on:
             d = {}
             for nm in L.BGC_DIAG_KC:
                 if nm not in L.BGC_DIAG_KC_UNTOUCHED:
-                    d[nm] = E((nz, ncol), **f64)
+                    d[nm] = KC()
             for nm in L.BGC_DIAG_KCA:
-                d[nm] = E((4, nz, ncol), **f64)
+                d[nm] = KC(4)
             for nm in L.BGC_DIAG_CA:
                 d[nm] = E((4, ncol), **f64)
             for nm in L.BGC_DIAG_C:
@@ -228,23 +256,20 @@ class Workload:
             self.surf = dict(forcing=s, flux=[flux[nm] for nm in ("depositionFlux", "riverFlux", "gasFlux", "seaIceFlux")],
                              flux0=None, ice0=None, net=E((30, ncol), **f64),
                              diag={nm: E((ncol,), **f64) for nm in L.BGC_FLUX_DIAG} if diag_on else None)
-        own = None
-        if "dms" in modules or "macros" in modules or "dms_surf" in modules:
-            own = E((5, nz, ncol), **f64)
-            extra.update(dms=own[0], dmsp=own[1], prot=own[2], poly=own[3], lip=own[4])
+        if with_own:
+            extra.update(dms=plane_of(own, 0), dmsp=plane_of(own, 1), prot=plane_of(own, 2), poly=plane_of(own, 3), lip=plane_of(own, 4))
         if extra:
-            eng.synth_fill_extra(nz, ncol, col0, **extra)
-        self.fused = bool(fused) and ("dms" in modules and "macros" in modules) and hasattr(eng, "fused_step")
+            eng.synth_fill_extra(nz, ncol, col0, tiled=self.tiled, ld=self.gkw.get("ld", 0), **extra)
         if "dms" in modules or "dms_surf" in modules:
-            dtr = None
-            if not self.fused or "dms_surf" in modules:     # the separate entry points read a 14-plane DMS tracer array
-                dtr = E((14, nz, ncol), **f64)
-                dtr[0].copy_(own[0]); dtr[1].copy_(own[1])
+            if dtr is not None:     # the separate entry points read a 14-plane DMS tracer array
+                view_of(dtr, 0).copy_(view_of(own, 0)); view_of(dtr, 1).copy_(view_of(own, 1))
                 for j, nm in enumerate(L.DMS_TRACERS[2:], start=2):
-                    dtr[j].copy_(self.tr[L.BGC_TRACERS.index(nm)])
-            self.dms = dict(tr=dtr, own=own[0:2], tend=E((2 if self.fused else 14, nz, ncol), **f64),
-                            diag=({} if null_diag else {nm: E((nz, ncol), **f64) for nm in L.DMS_DIAG_KC}) if diag_on else None,
-                            sst=self.kc["temp"][0].contiguous(),
+                    view_of(dtr, j).copy_(view_of(self.tr, L.BGC_TRACERS.index(nm)))
+            dtend = KC(2 if self.fused else 14)
+            self.dms = dict(tr=dtr, own=[plane_of(own, 0), plane_of(own, 1)], tend=dtend,
+                            tend_own=[plane_of(dtend, 0), plane_of(dtend, 1)] if self.fused else None,
+                            diag=({} if null_diag else {nm: KC() for nm in L.DMS_DIAG_KC}) if diag_on else None,
+                            sst=self.kc["temp"].surface_row() if self.tiled else self.kc["temp"][0].contiguous(),
                             net=E((14, ncol), **f64) if "dms_surf" in modules else None,
                             fdiag={nm: E((ncol,), **f64) for nm in L.DMS_FLUX_DIAG} if ("dms_surf" in modules and diag_on) else None)
         if "macros" in modules:
@@ -255,12 +280,14 @@ class Workload:
                     mtr[j].copy_(own[2 + j])
                 for j, nm in enumerate(L.MACROS_TRACERS[3:], start=3):
                     mtr[j].copy_(self.tr[L.BGC_TRACERS.index(nm)])
-            self.macros = dict(tr=mtr, own=own[2:5], tend=E((3 if self.fused else 8, nz, ncol), **f64),
-                               diag=({} if null_diag else {nm: E((nz, ncol), **f64) for nm in L.MACROS_DIAG_KC}) if diag_on else None)
+            mtend = KC(3 if self.fused else 8)
+            self.macros = dict(tr=mtr, own=[plane_of(own, 2 + j) for j in range(3)], tend=mtend,
+                               tend_own=[plane_of(mtend, j) for j in range(3)] if self.fused else None,
+                               diag=({} if null_diag else {nm: KC() for nm in L.MACROS_DIAG_KC}) if diag_on else None)
         self.active_cells = int(torch.clamp(self.kmax, 0, nz).sum().item())
         self.per_cell = 30 + (2 if "dms" in modules else 0) + (3 if "macros" in modules else 0)
         self.updates_per_step = self.active_cells * self.per_cell
-        CF = L.OBGC_LAYOUT_COLFAST
+        CF = self.layout
         kc, cc = self.kc, self.cc
         # the argument blocks of the calls are built once, as a compiled host would: the arrays do not move between steps
         if self.fused:
@@ -268,15 +295,16 @@ class Workload:
                                                     cc["lat"], self.kmax, kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"],
                                                     self.tend, p[0], p[1], self.diag, True,
                                                     dms=self.dms["own"][0], dmsp=self.dms["own"][1], SST=self.dms["sst"],
-                                                    dms_tend=self.dms["tend"][0], dmsp_tend=self.dms["tend"][1], dms_diag=self.dms["diag"],
+                                                    dms_tend=self.dms["tend_own"][0], dmsp_tend=self.dms["tend_own"][1],
+                                                    dms_diag=self.dms["diag"],
                                                     prot=self.macros["own"][0], poly=self.macros["own"][1], lip=self.macros["own"][2],
-                                                    prot_tend=self.macros["tend"][0], poly_tend=self.macros["tend"][1],
-                                                    lip_tend=self.macros["tend"][2], macros_diag=self.macros["diag"])
+                                                    prot_tend=self.macros["tend_own"][0], poly_tend=self.macros["tend_own"][1],
+                                                    lip_tend=self.macros["tend_own"][2], macros_diag=self.macros["diag"], **self.gkw)
                              for p in self.phs]
         else:
             self.prepared = [eng.bgc_source_sink_prepare(nz, ncol, CF, self.tr, kc["temp"], kc["salt"], kc["zmid"], kc["dz"], kc["zbot"],
                                                          cc["lat"], self.kmax, kc["fesedflux"], cc["dust_flux_in"], cc["sw_flux"],
-                                                         self.tend, p[0], p[1], self.diag, True)
+                                                         self.tend, p[0], p[1], self.diag, True, **self.gkw)
                              for p in self.phs]
         self.kms = {"call": [], "carbonate": [], "ecosys": [], "cell": [], "dms": [], "macros": []}
         torch.cuda.synchronize()
@@ -288,7 +316,7 @@ class Workload:
 
     def step(self, i, record):
         eng, L, torch = self.eng, self.L, self.torch
-        CF = L.OBGC_LAYOUT_COLFAST
+        CF = self.layout
         nz, ncol = self.nz, self.ncol
         if self.surf is not None:
             e = self.surf
@@ -299,10 +327,10 @@ class Workload:
             e["forcing"]["iceFraction"].copy_(e["ice0"])
             torch.cuda.synchronize()      # torch's stream -> engine's streams
             if "surf" in self.modules:     # the host model calls *_SurfaceFluxes before *_SourceSink
-                eng.bgc_surface_fluxes(nz, ncol, CF, self.tr, e["forcing"], *e["flux"], e["net"], e["diag"])
+                eng.bgc_surface_fluxes(nz, ncol, CF, self.tr, e["forcing"], *e["flux"], e["net"], e["diag"], **self.gkw)
             if "dms_surf" in self.modules:
                 d = self.dms
-                eng.dms_surface_fluxes(nz, ncol, CF, d["tr"], e["forcing"], d["net"], d["fdiag"])
+                eng.dms_surface_fluxes(nz, ncol, CF, d["tr"], e["forcing"], d["net"], d["fdiag"], **self.gkw)
         if self.fused:
             eng.fused_step_run(self.prepared[i % self.nbuf])
         else:
@@ -325,7 +353,7 @@ class Workload:
 
     def rezero(self):
         for p in self.phs:
-            p.zero_()
+            p[0].zero_(); p[1].zero_()
         self.torch.cuda.synchronize()
 
     def timed(self, steps, warmup, barrier):
@@ -347,15 +375,16 @@ class Workload:
         return time.perf_counter() - t0
 
     def workload_name(self):
-        return ("%s: %d columns x %d levels per GPU, %s%s, native column-fastest layout, diagnostics=%s, %s"
+        return ("%s: %d columns x %d levels per GPU, %s%s, %s, diagnostics=%s, %s"
                 % (self.name, self.ncol, self.nz, "+".join(self.modules), " (one fused call)" if self.fused else "",
+                   "column-block layout (64-column blocks, one arena)" if self.tiled else "native column-fastest layout",
                    "full" if self.diag_on else "none",
                    "cold pH bracket every step" if self.ph == "cold" else "warm pH brackets (previous step)"))
 
 
-def short_run(eng, torch, L, name, diag_on, ph, steps, warmup, fused):
+def short_run(eng, torch, L, name, diag_on, ph, steps, warmup, fused, layout="tiled"):
     ncol, nz, modules = CONFIGS[name]
-    w = Workload(eng, torch, L, name, ncol, nz, modules, 0, diag_on, ph, steps, fused)
+    w = Workload(eng, torch, L, name, ncol, nz, modules, 0, diag_on, ph, steps, fused, layout)
     el = w.timed(steps, warmup, torch.cuda.synchronize)
     out = {"workload": w.workload_name(), "value": w.updates_per_step * steps / el, "unit": "updates/s", "steps": steps,
            "ms_per_step": el / steps * 1e3}
@@ -481,6 +510,9 @@ def main():
                     help="weak (default, what a scaling run uses): the config's columns on EVERY GPU; strong: the config's "
                          "columns split over the GPUs")
     ap.add_argument("--separate", action="store_true", help="cfg4 / cfg5: three separate calls instead of the fused step")
+    ap.add_argument("--layout", default="tiled", choices=("tiled", "colfast"),
+                    help="tiled (default): blocks of 64 columns, every level-dependent array a set of rows of one arena "
+                         "(OBGC_LAYOUT_TILED); colfast: one plane per field (OBGC_LAYOUT_COLFAST)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short cfg2 / cfg3 / warm-bracket runs of the N = 1 line")
     args = ap.parse_args()
@@ -536,7 +568,7 @@ def main():
         col0, ncol = shard(rank, world, ncol)
     diag_on = args.diag == "full"
     eng = Engine(local_rank)
-    w = Workload(eng, torch, L, args.config, ncol, nz, modules, col0, diag_on, args.ph, args.steps, not args.separate)
+    w = Workload(eng, torch, L, args.config, ncol, nz, modules, col0, diag_on, args.ph, args.steps, not args.separate, args.layout)
 
     def barrier():
         torch.cuda.synchronize()
@@ -568,7 +600,7 @@ def main():
                 if not key.startswith("headline") and name == args.config:
                     continue
                 try:
-                    extras[key] = short_run(eng, torch, L, name, dg, ph, st, 2, not args.separate)
+                    extras[key] = short_run(eng, torch, L, name, dg, ph, st, 2, not args.separate, args.layout)
                 except Exception as exc:      # never lose the headline over an extra
                     extras[key] = {"failed": repr(exc)}
             out["other_workloads"] = extras

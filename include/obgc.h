@@ -67,8 +67,19 @@ typedef enum {
  *            then tracer/autotroph plane (BGC_parms.F90:128-132).
  *  COLFAST = the engine's native order X[n][k][column]: column fastest.  A host that
  *            keeps its tracers resident on the GPU should use this one: all kernels
- *            then read and write fully coalesced rows. */
-typedef enum { OBGC_LAYOUT_KFAST = 0, OBGC_LAYOUT_COLFAST = 1 } obgc_layout;
+ *            then read and write fully coalesced rows.
+ *  TILED   = column blocks: the columns are cut into blocks of 64 and element (k, c) of plane n lives at
+ *              base + (c / 64) * ld * nlev + k * ld + n * plane + c % 64
+ *            where `ld` (>= 64) is the distance between consecutive levels of one block and `plane` (default 64)
+ *            the distance between the planes of one array.  Arrays that share `ld` interleave row by row in ONE
+ *            allocation: give each array the address of its first 64-element row inside a common
+ *            arena[nblocks][nlev][ld] (nblocks = ceil(ncol / 64)); a block's rows of one level are then a
+ *            single contiguous run of ld * 8 bytes and a workgroup of the column kernel streams through ONE region of
+ *            memory instead of ~240 planes (+13 % sustained bandwidth for this access pattern on MI355X).  DEVICE
+ *            memory only; accepted by obgc_bgc_source_sink, obgc_fused_step, the two *_surface_fluxes,
+ *            obgc_apply_tendencies, the *_diag_accumulate family and obgc_synth_fill*; with BGC diagnostics the four
+ *            production profiles photoC, photoC_NO3, CaCO3_form and bSi_form must be among them. */
+typedef enum { OBGC_LAYOUT_KFAST = 0, OBGC_LAYOUT_COLFAST = 1, OBGC_LAYOUT_TILED = 2 } obgc_layout;
 typedef enum { OBGC_MEM_HOST = 0, OBGC_MEM_DEVICE = 1 } obgc_memspace;
 
 enum { OBGC_ASYNC = 1u };      /* obgc_create flag: device-memory calls return after enqueue */
@@ -78,6 +89,7 @@ enum { OBGC_ASYNC = 1u };      /* obgc_create flag: device-memory calls return a
  * tracer / autotroph planes (>= ld*ncol; ld*numColumnsMax when the host array is
  * larger than the batch).  For COLFAST `ld` is the distance between consecutive
  * levels (>= ncol) and `plane` the distance between planes (>= ld*nlev).
+ * For TILED (`ld` is required) see the layout enumeration above.
  * plane == 0 selects the dense default. (column) and (column,n) arrays are always
  * column-fastest with plane stride `ldc` (>= ncol; 0 = ncol). */
 typedef struct {
@@ -321,7 +333,7 @@ int obgc_macros_source_sink(obgc_handle *h, const obgc_macros_source_sink_args *
  *     five tendency planes of the shared tracers, which the reference leaves zero, are not written.
  *   - cells below kmax: the own tendencies are zero-filled, DMS / MACROS diagnostics are left alone (as the reference).
  *   - dms == NULL skips DMS, prot == NULL skips MACROS; both NULL is obgc_bgc_source_sink.
- *   - DEVICE pointers in the native COLFAST layout only (OBGC_ERR_UNSUPPORTED otherwise). */
+ *   - DEVICE pointers in the native COLFAST layout or in the TILED layout only (OBGC_ERR_UNSUPPORTED otherwise). */
 typedef struct {
   obgc_bgc_source_sink_args bgc;
   const double *dms, *dmsp;               /* DMS_tracers(k,column,dms_ind / dmsp_ind) */
@@ -469,6 +481,7 @@ typedef struct {
   double *tracers, *temp, *salt, *zmid, *dz, *zbot, *fesedflux;
   double *lat, *dust_flux_in, *sw_flux;
   int *kmax;
+  int tiled;                  /* 0: COLFAST strides (ld, plane); 1: OBGC_LAYOUT_TILED with the same two numbers */
 } obgc_synth_args;
 int obgc_synth_fill(obgc_handle *h, const obgc_synth_args *a);
 /* The rest of the same workload: the (column) forcing of BGC_SurfaceFluxes / DMS_SurfaceFluxes
@@ -483,6 +496,7 @@ typedef struct {
   double *surface_pH, *surface_pH_alt_co2;            /* zero: no previous solution */
   double *depositionFlux, *riverFlux, *gasFlux, *seaIceFlux;
   double *dms, *dmsp, *prot, *poly, *lip;
+  int tiled;                  /* as in obgc_synth_args, for the five (k,column) planes */
 } obgc_synth_extra_args;
 int obgc_synth_fill_extra(obgc_handle *h, const obgc_synth_extra_args *a);
 

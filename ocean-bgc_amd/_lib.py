@@ -37,7 +37,7 @@ AUTOTROPH_INTS = _xlist("OBGC_AUTOTROPH_INTS")
 AUTOTROPH_REALS = _xlist("OBGC_AUTOTROPH_REALS")
 BGC_DIAG_KC_UNTOUCHED = ["POC_ACCUM", "DONr_remin", "DOPr_remin"]
 
-OBGC_LAYOUT_KFAST, OBGC_LAYOUT_COLFAST = 0, 1
+OBGC_LAYOUT_KFAST, OBGC_LAYOUT_COLFAST, OBGC_LAYOUT_TILED = 0, 1, 2
 OBGC_MEM_HOST, OBGC_MEM_DEVICE = 0, 1
 OBGC_ASYNC = 1
 STATUS = {0: "OBGC_OK", -1: "OBGC_ERR_INVALID", -2: "OBGC_ERR_NO_DEVICE", -3: "OBGC_ERR_HIP",
@@ -144,7 +144,7 @@ class SynthArgs(C.Structure):
     _fields_ = [("nlev", C.c_int), ("ncol", C.c_int), ("col0", C.c_longlong), ("ld", C.c_longlong),
                 ("plane", C.c_longlong), ("ldc", C.c_longlong), ("ind", C.POINTER(C.c_int)), ("tracers", _dptr),
                 ("temp", _dptr), ("salt", _dptr), ("zmid", _dptr), ("dz", _dptr), ("zbot", _dptr), ("fesedflux", _dptr),
-                ("lat", _dptr), ("dust_flux_in", _dptr), ("sw_flux", _dptr), ("kmax", _dptr)]
+                ("lat", _dptr), ("dust_flux_in", _dptr), ("sw_flux", _dptr), ("kmax", _dptr), ("tiled", C.c_int)]
 
 
 SYNTH_EXTRA_FIELDS = ("surfacePressure", "iceFraction", "windSpeedSquared10m", "atmCO2", "atmCO2_ALT_CO2", "surfaceDepth", "SST",
@@ -154,7 +154,7 @@ SYNTH_EXTRA_FIELDS = ("surfacePressure", "iceFraction", "windSpeedSquared10m", "
 
 class SynthExtraArgs(C.Structure):
     _fields_ = [("nlev", C.c_int), ("ncol", C.c_int), ("col0", C.c_longlong), ("ld", C.c_longlong), ("ldc", C.c_longlong)] + \
-        [(n, _dptr) for n in SYNTH_EXTRA_FIELDS]
+        [(n, _dptr) for n in SYNTH_EXTRA_FIELDS] + [("tiled", C.c_int)]
 
 
 # every symbol include/obgc.h declares, with its prototype

@@ -106,12 +106,35 @@ const char* kMacLong[8] = {"Proteins", "Polysaccharides", "Lipids", "Zooplankton
 
 bool grid_ok(const obgc_grid& g) {
   if (g.nlev < 1 || g.ncol < 0) return false;
-  if (g.layout != OBGC_LAYOUT_KFAST && g.layout != OBGC_LAYOUT_COLFAST) return false;
+  if (g.layout != OBGC_LAYOUT_KFAST && g.layout != OBGC_LAYOUT_COLFAST && g.layout != OBGC_LAYOUT_TILED) return false;
   if (g.memspace != OBGC_MEM_HOST && g.memspace != OBGC_MEM_DEVICE) return false;
+  if (g.layout == OBGC_LAYOUT_TILED) {   // column blocks: device memory, an explicit level stride, planes inside it
+    if (g.memspace != OBGC_MEM_DEVICE || g.ld < 64) return false;
+    if (g.plane != 0 && (g.plane < 64 || g.plane > g.ld)) return false;
+    return g.ldc == 0 || g.ldc >= g.ncol;
+  }
   const long long minld = (g.layout == OBGC_LAYOUT_KFAST) ? g.nlev : g.ncol;
   if (g.ld != 0 && g.ld < minld) return false;
   if (g.ldc != 0 && g.ldc < g.ncol) return false;
   return true;
+}
+
+// The column-block layout is served by the column-block kernel with the carbonate solve inside: one launch and the
+// column integrals of the production profiles, which read the caller's own photoC / photoC_NO3 / CaCO3_form / bSi_form.
+int tiled_ok(obgc_handle* h, const obgc_bgc_diag* d, const char* who) {
+  if (!h->column)
+    return fail(h, OBGC_ERR_UNSUPPORTED, std::string(who) + ": the TILED layout needs the column-block kernel (OBGC_COLUMN_KERNEL=0 is set)");
+  if (d && !(d->photoC && d->photoC_NO3 && d->CaCO3_form && d->bSi_form))
+    return fail(h, OBGC_ERR_UNSUPPORTED, std::string(who) + ": TILED layout with diagnostics needs photoC, photoC_NO3, CaCO3_form and bSi_form "
+                "among them (the column integrals read them; the engine keeps no scratch in the caller's index space)");
+  return OBGC_OK;
+}
+
+// entry points whose scratch lives in the caller's index space do not take the column-block layout
+int no_tiled(obgc_handle* h, const obgc_grid& g, const char* who) {
+  if (g.layout != OBGC_LAYOUT_TILED) return OBGC_OK;
+  return fail(h, OBGC_ERR_UNSUPPORTED, std::string(who) + ": the TILED layout is served by obgc_bgc_source_sink, obgc_fused_step, the "
+              "*_surface_fluxes, obgc_apply_tendencies and the accumulate family only");
 }
 
 // bytes spanned by `nplanes` planes of a (k,column) array
@@ -390,6 +413,7 @@ namespace {
 // integral goes through memory
 // whether the column-block kernel solves the carbonate system in its own wavefronts (schedule 3) for this view
 bool column_fuses(const obgc_handle* h, const GridView& kv, bool have_diag) {
+  if (kv.tiled) return true;   // one launch, no scratch planes: nothing of the engine's own lives in the caller's index space
   const bool large = (long long)kv.nlev * kv.ncol > 10000000LL;
   return h->sched == 2 || (h->sched < 0 && large && have_diag);
 }
@@ -778,6 +802,9 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   HIP_TRY(h, hipSetDevice(h->device));
   const GridView v = make_view(a->grid);
   if (v.ncol == 0) return OBGC_OK;
+  if (v.tiled) {
+    if (int rc = tiled_ok(h, a->diag, "obgc_bgc_source_sink")) return rc;
+  }
   h->arena_used = 0;
   h->timed_valid = false;
   h->tr_valid = false;
@@ -990,10 +1017,13 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   const obgc_bgc_source_sink_args& b = a->bgc;
   if (!grid_ok(b.grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
   if (!a->dms && !a->prot) return obgc_bgc_source_sink(h, &a->bgc);   // nothing to fuse
-  if (b.grid.memspace != OBGC_MEM_DEVICE || b.grid.layout != OBGC_LAYOUT_COLFAST)
+  if (b.grid.memspace != OBGC_MEM_DEVICE || b.grid.layout == OBGC_LAYOUT_KFAST)
     return fail(h, OBGC_ERR_UNSUPPORTED,
-                "obgc_fused_step: device pointers in the native column-fastest layout only; for host memory or the reference "
-                "layout call obgc_bgc_source_sink, obgc_dms_source_sink and obgc_macros_source_sink");
+                "obgc_fused_step: device pointers in the native column-fastest or column-block layout only; for host memory or the "
+                "reference layout call obgc_bgc_source_sink, obgc_dms_source_sink and obgc_macros_source_sink");
+  if (b.grid.layout == OBGC_LAYOUT_TILED) {
+    if (int rc = tiled_ok(h, b.diag, "obgc_fused_step")) return rc;
+  }
   if (b.grid.ncol == 0) return OBGC_OK;
   if (!b.tracers || !b.temp || !b.salt || !b.zmid || !b.dz || !b.zbot || !b.lat || !b.kmax || !b.fesedflux || !b.dust_flux_in ||
       !b.sw_flux || !b.tend || !b.ph_prev || !b.ph_prev_alt)
@@ -1167,6 +1197,7 @@ extern "C" int obgc_dms_source_sink(obgc_handle* h, const obgc_dms_source_sink_a
   if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->tracers || !a->dz || !a->kmax || !a->SST || !a->sw_flux || !a->tend)
     return fail(h, OBGC_ERR_INVALID, "obgc_dms_source_sink: null array");
+  if (int rc = no_tiled(h, a->grid, "obgc_dms_source_sink")) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
   const GridView v = make_view(a->grid);
   if (v.ncol == 0) return OBGC_OK;
@@ -1282,6 +1313,7 @@ extern "C" int obgc_macros_source_sink(obgc_handle* h, const obgc_macros_source_
   if (!grid_ok(a->grid)) return fail(h, OBGC_ERR_INVALID, "bad obgc_grid");
   if (a->grid.ncol == 0) return OBGC_OK;   // numColumns = 0: the reference's loops do not execute; arrays may be NULL
   if (!a->tracers || !a->kmax || !a->tend) return fail(h, OBGC_ERR_INVALID, "obgc_macros_source_sink: null array");
+  if (int rc = no_tiled(h, a->grid, "obgc_macros_source_sink")) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
   const GridView v = make_view(a->grid);
   if (v.ncol == 0) return OBGC_OK;
@@ -1449,6 +1481,7 @@ extern "C" int obgc_accumulate_arrays(obgc_handle* h, const obgc_grid* grid, int
 
 extern "C" int obgc_synth_fill(obgc_handle* h, const obgc_synth_args* a) {
   if (!h || !a || a->nlev < 1 || a->ncol < 0) return OBGC_ERR_INVALID;
+  if (a->tiled && a->ld < 64) return fail(h, OBGC_ERR_INVALID, "obgc_synth_fill: the TILED layout needs its level stride ld");
   HIP_TRY(h, hipSetDevice(h->device));
   launch_synth(*a, a->ind, h->s_main);
   HIP_TRY(h, hipGetLastError());
@@ -1458,7 +1491,8 @@ extern "C" int obgc_synth_fill(obgc_handle* h, const obgc_synth_args* a) {
 
 extern "C" int obgc_synth_fill_extra(obgc_handle* h, const obgc_synth_extra_args* a) {
   if (!h || !a || a->nlev < 1 || a->ncol < 0) return OBGC_ERR_INVALID;
-  if ((a->ld != 0 && a->ld < a->ncol) || (a->ldc != 0 && a->ldc < a->ncol)) return fail(h, OBGC_ERR_INVALID, "bad leading dimension");
+  if (a->tiled ? a->ld < 64 : (a->ld != 0 && a->ld < a->ncol)) return fail(h, OBGC_ERR_INVALID, "bad leading dimension");
+  if (a->ldc != 0 && a->ldc < a->ncol) return fail(h, OBGC_ERR_INVALID, "bad leading dimension");
   HIP_TRY(h, hipSetDevice(h->device));
   launch_synth_extra(*a, h->s_main);
   HIP_TRY(h, hipGetLastError());

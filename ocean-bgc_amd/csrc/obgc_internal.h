@@ -21,12 +21,13 @@
 namespace obgc {
 
 // Strided view of the level-dependent arrays of one call.  Element (k, c) of plane n
-// lives at  n*plane + k*sk + c*sc.   KFAST: sk = 1, sc = ld.   COLFAST: sk = ld, sc = 1.
+// lives at  n*plane + k*sk + c*sc + (c / 64)*sbx.   KFAST: sk = 1, sc = ld.   COLFAST: sk = ld, sc = 1.
+// TILED (blocks of 64 columns, a block's levels ld apart): sk = ld, sc = 1, sbx = ld*nlev - 64; sbx = 0 otherwise.
 struct GridView {
   int nlev, ncol;
-  long long sk, sc, plane, ldc;
-  int kfast;
-  __host__ __device__ inline long long at(int k, int c) const { return (long long)k * sk + (long long)c * sc; }
+  long long sk, sc, plane, ldc, sbx;
+  int kfast, tiled;
+  __host__ __device__ inline long long at(int k, int c) const { return (long long)k * sk + (long long)c * sc + (long long)(c >> 6) * sbx; }
 };
 
 inline GridView make_view(const obgc_grid& g) {
@@ -34,11 +35,20 @@ inline GridView make_view(const obgc_grid& g) {
   v.nlev = g.nlev;
   v.ncol = g.ncol;
   v.kfast = (g.layout == OBGC_LAYOUT_KFAST);
+  v.tiled = (g.layout == OBGC_LAYOUT_TILED);
+  v.ldc = g.ldc > 0 ? g.ldc : g.ncol;
+  if (v.tiled) {
+    v.sk = g.ld;
+    v.sc = 1;
+    v.sbx = g.ld * (long long)g.nlev - 64;
+    v.plane = g.plane > 0 ? g.plane : 64;
+    return v;
+  }
   long long ld = g.ld > 0 ? g.ld : (v.kfast ? g.nlev : g.ncol);
   v.sk = v.kfast ? 1 : ld;
   v.sc = v.kfast ? ld : 1;
+  v.sbx = 0;
   v.plane = g.plane > 0 ? g.plane : (v.kfast ? ld * (long long)g.ncol : ld * (long long)g.nlev);
-  v.ldc = g.ldc > 0 ? g.ldc : g.ncol;
   return v;
 }
 

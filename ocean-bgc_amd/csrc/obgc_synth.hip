@@ -1,5 +1,5 @@
 // On-device twin of ocean-bgc_amd/synth.py: deterministic synthetic columns in the native
-// COLFAST layout.  Only splitmix64 hashes and + - * / are used, and this file is built
+// COLFAST layout (or in blocks of 64 columns, OBGC_LAYOUT_TILED).  Only splitmix64 hashes and + - * / are used, and this file is built
 // with -ffp-contract=off, so every value is bit-identical to the numpy generator.
 // Workload utility for bench.py / tests, not part of the hot path.
 #include "obgc_internal.h"
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthArgs S) {
   if (idx >= ncell) return;
   const int cl = (int)(idx % a.ncol), k = (int)(idx / a.ncol);
   const unsigned long long c = (unsigned long long)(a.col0 + cl);
-  const long long ix = (long long)k * a.ld + cl;
+  const long long ix = (long long)k * a.ld + cl + (a.tiled ? (long long)(cl >> 6) * (a.ld * a.nlev - 64) : 0);
   const int nz = a.nlev;
   // grid
   const double kf = (double)k;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void synth_extra_kernel(const obgc_synth_extra
   if (idx >= ncell) return;
   const int cl = (int)(idx % a.ncol), k = (int)(idx / a.ncol);
   const unsigned long long c = (unsigned long long)(a.col0 + cl);
-  const long long ix = (long long)k * a.ld + cl;
+  const long long ix = (long long)k * a.ld + cl + (a.tiled ? (long long)(cl >> 6) * (a.ld * a.nlev - 64) : 0);
   const double kf = (double)k;
   const double dz = 1000.0 * (1.0 + 0.05 * kf);
   const double zbot = 1000.0 * ((kf + 1.0) + 0.025 * (kf * (kf + 1.0)));
@@ -192,7 +192,7 @@ void launch_synth(const obgc_synth_args& a, const int* ind30, hipStream_t s) {
   SynthArgs S;
   S.a = a;
   if (S.a.ld <= 0) S.a.ld = a.ncol;
-  if (S.a.plane <= 0) S.a.plane = S.a.ld * a.nlev;
+  if (S.a.plane <= 0) S.a.plane = a.tiled ? 64 : S.a.ld * a.nlev;
   for (int i = 0; i < 30; ++i) S.ind[i] = ind30 ? ind30[i] : i + 1;
   const long long ncell = (long long)a.nlev * a.ncol;
   if (ncell <= 0) return;

@@ -30,6 +30,71 @@ def make_grid(nlev, ncol, layout, memspace, ld=0, plane=0, ldc=0):
     return g
 
 
+class TileArena:
+    """ONE device allocation for every level-dependent array of a call in the column-block layout (OBGC_LAYOUT_TILED):
+    arena[nblock][nlev][nrows][64], block = 64 adjacent columns.  An array of n planes owns n consecutive rows; the C ABI
+    gets the address of its first row, grid.ld = nrows * 64 and grid.plane = 64."""
+
+    def __init__(self, torch, device, ncol, nlev, nrows):
+        self.torch, self.ncol, self.nlev, self.nrows = torch, int(ncol), int(nlev), int(nrows)
+        self.nblk = (self.ncol + 63) // 64
+        self.buf = torch.zeros((self.nblk, self.nlev, self.nrows, 64), dtype=torch.float64, device=device)
+        self.used = 0
+
+    @property
+    def ld(self):
+        return self.nrows * 64
+
+    def take(self, nplanes, shape=None):
+        if self.used + nplanes > self.nrows:
+            raise ObgcError("TileArena: %d rows are not enough" % self.nrows)
+        f = TileField(self, self.used, nplanes, shape)
+        self.used += nplanes
+        return f
+
+
+class TileField:
+    """n consecutive rows of a TileArena: what the C ABI sees as one (k,column[,n]) array."""
+    is_cuda = True
+
+    def __init__(self, arena, row, nplanes, shape):
+        self.arena, self.row, self.nplanes = arena, row, nplanes
+        self.shape = shape if shape is not None else (nplanes, arena.ncol, arena.nlev)
+
+    def data_ptr(self):
+        return self.arena.buf.data_ptr() + self.row * 64 * 8
+
+    def view(self):
+        return self.arena.buf[:, :, self.row:self.row + self.nplanes, :]          # [nblk, nlev, n, 64]
+
+    def sub(self, j, n=1):
+        """planes [j, j + n) of this array as an array of their own"""
+        return TileField(self.arena, self.row + j, n, (self.arena.ncol, self.arena.nlev) if n == 1 else None)
+
+    def zero_(self):
+        self.view().zero_()
+        return self
+
+    def surface_row(self, j=0):
+        """level 1 of plane j as a dense (ncol) device vector"""
+        return self.arena.buf[:, 0, self.row + j, :].reshape(-1)[:self.arena.ncol].contiguous()
+
+    def put(self, x):
+        """x: numpy [.., ncol, nlev] in the reference's order (leading extent = planes, may be absent)."""
+        A, torch = self.arena, self.arena.torch
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.nplanes, A.ncol, A.nlev)
+        pad = np.zeros((self.nplanes, A.nblk * 64, A.nlev))
+        pad[:, :A.ncol, :] = x
+        t = torch.from_numpy(pad.reshape(self.nplanes, A.nblk, 64, A.nlev)).to(A.buf.device)
+        self.view().copy_(t.permute(1, 3, 0, 2))
+        return self
+
+    def get(self):
+        A = self.arena
+        t = self.view().permute(2, 0, 3, 1).contiguous().cpu().numpy()              # [n, nblk, 64, nlev]
+        return t.reshape(self.nplanes, A.nblk * 64, A.nlev)[:, :A.ncol, :].reshape(self.shape).copy()
+
+
 def partition_columns(kmax, nparts, balance="cells"):
     """Contiguous column ranges for `nparts` devices (obgc_partition_columns; host-only, no GPU needed).
     balance: "columns" (equal counts) or "cells" (equal sums of active levels).  -> list of nparts+1 bounds."""
@@ -328,10 +393,11 @@ class Engine:
                                                     table(vecs, 0), table(vecs, 1), float(weight), 1 if reset else 0),
                     "obgc_accumulate_arrays")
 
-    def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, **dev_arrays):
-        """Fill device tensors (native COLFAST layout) with the synthetic workload."""
+    def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, tiled=False, **dev_arrays):
+        """Fill device tensors (native COLFAST layout, or column blocks with tiled=True) with the synthetic workload."""
         a = L.SynthArgs()
         a.nlev, a.ncol, a.col0, a.ld, a.plane, a.ldc = nlev, ncol, col0, ld, plane, 0
+        a.tiled = 1 if tiled else 0
         keep = (C.c_int * 30)(*[int(i) for i in ind]) if ind is not None else None
         a.ind = keep
         for nm in ("tracers", "temp", "salt", "zmid", "dz", "zbot", "fesedflux", "lat", "dust_flux_in", "sw_flux", "kmax"):
@@ -344,10 +410,11 @@ class Engine:
             setattr(a, nm, p)
         self._check(self.lib.obgc_synth_fill(self.h, C.byref(a)), "obgc_synth_fill")
 
-    def synth_fill_extra(self, nlev, ncol, col0, ld=0, ldc=0, **dev_arrays):
+    def synth_fill_extra(self, nlev, ncol, col0, ld=0, ldc=0, tiled=False, **dev_arrays):
         """Surface forcing, external fluxes and the DMS / MACROS own tracers of the synthetic workload (device tensors)."""
         a = L.SynthExtraArgs()
         a.nlev, a.ncol, a.col0, a.ld, a.ldc = nlev, ncol, col0, ld, ldc
+        a.tiled = 1 if tiled else 0
         for nm, x in dev_arrays.items():
             if nm not in L.SYNTH_EXTRA_FIELDS:
                 raise ObgcError("synth_fill_extra: unknown field %s" % nm)

@@ -14,14 +14,15 @@ same routines take numpy arrays in exactly that memory order -- C-order shape [n
 `path` selects how the arrays reach the kernels (every path ends in the same HIP kernels):
   "host"            host pointers, reference layout: staged H2D/D2H by the library
   "device_kfast"    device pointers, reference layout
-  "device_colfast"  device pointers, native column-fastest layout (what bench.py times)
+  "device_colfast"  device pointers, native column-fastest layout
+  "device_tiled"    device pointers, column blocks of 64 in one arena (OBGC_LAYOUT_TILED; what bench.py times)
 """
 import numpy as np
 
 from . import _lib as L
-from .engine import Engine, ObgcError
+from .engine import Engine, ObgcError, TileArena, TileField
 
-PATHS = ("host", "device_kfast", "device_colfast")
+PATHS = ("host", "device_kfast", "device_colfast", "device_tiled")
 
 
 def _torch():
@@ -71,12 +72,25 @@ class ColumnEngine:
         return [tuple(self.eng.lib.obgc_tracer_name(module, i, w).decode() for w in range(3)) for i in range(1, n + 1)]
 
     # ---- array plumbing ----
+    def _begin(self, nc, nz, nrows):
+        """Column-block path: one arena of `nrows` 64-column rows per (block, level) for the (k,column) arrays of this call."""
+        self._arena = TileArena(_torch(), "cuda:%d" % self.device, nc, nz, nrows) if self.path == "device_tiled" else None
+
+    @property
+    def _gkw(self):
+        """leading dimensions of the call's grid"""
+        return dict(ld=self._arena.ld, plane=64) if self.path == "device_tiled" else {}
+
     def _up(self, x, kind):
         """host reference-layout array -> what the selected path hands to the C ABI.
         kind: 'kc' [.., ncol, nlev]; 'c' per-column / (column,n) arrays."""
         x = np.ascontiguousarray(x)
         if self.path == "host":
             return x.copy()
+        if self.path == "device_tiled" and kind == "kc":
+            f = self._arena.take(x.shape[0] if x.ndim == 3 else 1, x.shape).put(x)
+            self._ready()
+            return f
         torch = _torch()
         t = torch.from_numpy(x).to("cuda:%d" % self.device)
         if self.path == "device_colfast" and kind == "kc":
@@ -87,6 +101,8 @@ class ColumnEngine:
     def _down(self, t, kind):
         if isinstance(t, np.ndarray):
             return t
+        if isinstance(t, TileField):
+            return t.get()
         if self.path == "device_colfast" and kind == "kc":
             t = t.transpose(-1, -2).contiguous()
         return t.cpu().numpy()
@@ -100,12 +116,18 @@ class ColumnEngine:
 
     @property
     def _layout(self):
-        return L.OBGC_LAYOUT_COLFAST if self.path == "device_colfast" else L.OBGC_LAYOUT_KFAST
+        return {"device_colfast": L.OBGC_LAYOUT_COLFAST, "device_tiled": L.OBGC_LAYOUT_TILED}.get(self.path, L.OBGC_LAYOUT_KFAST)
+
+    @staticmethod
+    def _bgc_rows(diagnostics):
+        """rows of a column-block arena for BGC_SourceSink: 30 tracers, 6 fields, 30 tendencies, 2 pH (+ diagnostics)"""
+        return 68 + (len(L.BGC_DIAG_KC) + 4 * len(L.BGC_DIAG_KCA) if diagnostics else 0)
 
     # ---- BGC_SourceSink (BGC_mod.F90:340) ----
     def BGC_SourceSink(self, tracers, temp, salt, zmid, dz, zbot, lat, kmax, fesed, dust, sw, ph_prev, ph_prev_alt,
                        alt_co2_use_eco=True, diag_init=0.0, diagnostics=True):
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, self._bgc_rows(diagnostics))
         up = self._up
         tend = up(np.full((30, nc, nz), diag_init), "kc")
         php, pha = up(ph_prev, "kc"), up(ph_prev_alt, "kc")
@@ -122,7 +144,7 @@ class ColumnEngine:
                 diag[nm] = up(np.full((nc,), diag_init), "c")
         self.eng.bgc_source_sink(nz, nc, self._layout, up(tracers, "kc"), up(temp, "kc"), up(salt, "kc"), up(zmid, "kc"),
                                  up(dz, "kc"), up(zbot, "kc"), up(lat, "c"), up(np.asarray(kmax, dtype=np.int32), "c"),
-                                 up(fesed, "kc"), up(dust, "c"), up(sw, "c"), tend, php, pha, diag, alt_co2_use_eco)
+                                 up(fesed, "kc"), up(dust, "c"), up(sw, "c"), tend, php, pha, diag, alt_co2_use_eco, **self._gkw)
         out = dict(tend=self._down(tend, "kc"), ph_prev=self._down(php, "kc"), ph_prev_alt=self._down(pha, "kc"),
                    kc={}, kca={}, ca={}, c={})
         if diagnostics:
@@ -139,9 +161,10 @@ class ColumnEngine:
         prot, poly, lip at the slots of the engine's DMS / MACROS indices) are handed to the library, the shared ones must be
         copies of the BGC tracers (asserted).  Returns {"bgc", "dms", "macros"} shaped like the three separate routines'
         results; the tendency planes of the shared tracers, which the fused step does not write, are returned as zeros."""
-        if self.path != "device_colfast":
-            raise ValueError("the fused step runs on device-resident arrays in the native layout")
+        if self.path not in ("device_colfast", "device_tiled"):
+            raise ValueError("the fused step runs on device-resident arrays in the native or the column-block layout")
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, self._bgc_rows(diagnostics) + 10 + (len(L.DMS_DIAG_KC) + len(L.MACROS_DIAG_KC) if diagnostics else 0))
         up = self._up
         E = self.eng
         tend = up(np.full((30, nc, nz), diag_init), "kc")
@@ -178,7 +201,7 @@ class ColumnEngine:
                 mdiag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.MACROS_DIAG_KC}
         E.fused_step(nz, nc, self._layout, up(tracers, "kc"), up(temp, "kc"), up(salt, "kc"), up(zmid, "kc"), up(dz, "kc"),
                      up(zbot, "kc"), up(lat, "c"), up(np.asarray(kmax, dtype=np.int32), "c"), up(fesed, "kc"), up(dust, "c"),
-                     up(sw, "c"), tend, php, pha, diag, alt_co2_use_eco, dms_diag=ddiag, macros_diag=mdiag, **own)
+                     up(sw, "c"), tend, php, pha, diag, alt_co2_use_eco, dms_diag=ddiag, macros_diag=mdiag, **own, **self._gkw)
         dn = self._down
         bgc = dict(tend=dn(tend, "kc"), ph_prev=dn(php, "kc"), ph_prev_alt=dn(pha, "kc"), kc={}, kca={}, ca={}, c={})
         if diagnostics:
@@ -202,12 +225,13 @@ class ColumnEngine:
     def BGC_SurfaceFluxes(self, tracers, forcing, depo, river, gas, seaice, net=None, lcalc_o2=True, lcalc_co2=True,
                           diag_init=0.0):
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, 30)
         up = self._up
         f = {nm: up(np.asarray(v, dtype=np.float64), "c") for nm, v in forcing.items()}
         d, r, g, s = (up(x, "c") for x in (depo, river, gas, seaice))
         netf = up(np.full((30, nc), diag_init) if net is None else net, "c")
         fd = {nm: up(np.full((nc,), diag_init), "c") for nm in L.BGC_FLUX_DIAG}
-        self.eng.bgc_surface_fluxes(nz, nc, self._layout, up(tracers, "kc"), f, d, r, g, s, netf, fd, lcalc_o2, lcalc_co2)
+        self.eng.bgc_surface_fluxes(nz, nc, self._layout, up(tracers, "kc"), f, d, r, g, s, netf, fd, lcalc_o2, lcalc_co2, **self._gkw)
         dn = self._down
         return dict(forcing={nm: dn(v, "c") for nm, v in f.items()}, depositionFlux=dn(d, "c"), riverFlux=dn(r, "c"),
                     gasFlux=dn(g, "c"), seaIceFlux=dn(s, "c"), netFlux=dn(netf, "c"),
@@ -216,21 +240,23 @@ class ColumnEngine:
     # ---- DMS (DMS_mod.F90:156, 778) ----
     def DMS_SourceSink(self, tracers, dz, kmax, sst, sw, diag_init=0.0):
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, 14 + 1 + 14 + len(L.DMS_DIAG_KC))
         up = self._up
         tend = up(np.full((14, nc, nz), diag_init), "kc")
         diag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.DMS_DIAG_KC}
         self.eng.dms_source_sink(nz, nc, self._layout, up(tracers, "kc"), up(dz, "kc"),
-                                 up(np.asarray(kmax, dtype=np.int32), "c"), up(sst, "c"), up(sw, "c"), tend, diag)
+                                 up(np.asarray(kmax, dtype=np.int32), "c"), up(sst, "c"), up(sw, "c"), tend, diag, **self._gkw)
         return dict(tend=self._down(tend, "kc"), kc={nm: self._down(v, "kc") for nm, v in diag.items()})
 
     def DMS_SurfaceFluxes(self, tracers, forcing, net=None, lcalc=True, diag_init=0.0):
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, 14)
         up = self._up
         f = {nm: up(np.asarray(forcing[nm], dtype=np.float64), "c")
              for nm in ("surfacePressure", "iceFraction", "windSpeedSquared10m", "SST", "SSS")}
         netf = up(np.full((14, nc), diag_init) if net is None else net, "c")
         fd = {nm: up(np.full((nc,), diag_init), "c") for nm in L.DMS_FLUX_DIAG}
-        self.eng.dms_surface_fluxes(nz, nc, self._layout, up(tracers, "kc"), f, netf, fd, lcalc)
+        self.eng.dms_surface_fluxes(nz, nc, self._layout, up(tracers, "kc"), f, netf, fd, lcalc, **self._gkw)
         dn = self._down
         return dict(forcing={nm: dn(v, "c") for nm, v in f.items()}, netFlux=dn(netf, "c"),
                     fdiag={nm: dn(v, "c") for nm, v in fd.items()})
@@ -241,19 +267,21 @@ class ColumnEngine:
         if self.path == "host":
             raise ValueError("apply_tendencies needs a device path: the point is tracers that stay on the GPU")
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, 2 * n + 1)
         up = self._up
         x = up(tracers, "kc")
         self.eng.apply_tendencies(nz, nc, self._layout, x, up(tend, "kc"), up(np.asarray(kmax, dtype=np.int32), "c"), dt,
                                   None if net_flux is None else up(net_flux, "c"), None if dz is None else up(dz, "kc"),
-                                  clamp_nonneg)
+                                  clamp_nonneg, **self._gkw)
         return self._down(x, "kc")
 
     # ---- MACROS (MACROS_mod.F90:137) ----
     def MACROS_SourceSink(self, tracers, kmax, diag_init=0.0):
         n, nc, nz = tracers.shape
+        self._begin(nc, nz, 8 + 8 + len(L.MACROS_DIAG_KC))
         up = self._up
         tend = up(np.full((8, nc, nz), diag_init), "kc")
         diag = {nm: up(np.full((nc, nz), diag_init), "kc") for nm in L.MACROS_DIAG_KC}
         self.eng.macros_source_sink(nz, nc, self._layout, up(tracers, "kc"), up(np.asarray(kmax, dtype=np.int32), "c"),
-                                    tend, diag)
+                                    tend, diag, **self._gkw)
         return dict(tend=self._down(tend, "kc"), kc={nm: self._down(v, "kc") for nm, v in diag.items()})
