@@ -74,15 +74,18 @@ def shard_strong(rank, world, total):
 
 
 def reduce_results(dist, elapsed, updates, device):
-    """max-over-ranks of the wall time, sum-over-ranks of the work; no data-path collective."""
+    """max-over-ranks of the wall time, sum-over-ranks of the work; no data-path collective.
+    -> (slowest rank's seconds, updates of all ranks, fastest rank's seconds)"""
     if dist is None:
-        return elapsed, float(updates)
+        return elapsed, float(updates), elapsed
     import torch
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     u = torch.tensor([float(updates)], dtype=torch.float64, device=device)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
-    return float(t.item()), float(u.item())
+    lo = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float(t.item()), float(u.item()), float(lo.item())
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -206,6 +209,7 @@ class Workload:
             if diag_on:
                 nrows += len(L.BGC_DIAG_KC) - len(L.BGC_DIAG_KC_UNTOUCHED) + 4 * len(L.BGC_DIAG_KCA)
                 nrows += (len(L.DMS_DIAG_KC) if "dms" in modules else 0) + (len(L.MACROS_DIAG_KC) if "macros" in modules else 0)
+            nrows += int(os.environ.get("OBGC_BENCH_TILE_PAD", "0"))      # experiment knob: unused rows at the end of every tile
             self.arena = TileArena(torch, dev, ncol, nz, nrows)
             KC = lambda n=1: self.arena.take(n, (ncol, nz) if n == 1 else None)
             self.gkw = dict(ld=self.arena.ld, plane=64)
@@ -393,6 +397,46 @@ def short_run(eng, torch, L, name, diag_on, ph, steps, warmup, fused, layout="ti
     return out
 
 
+def end_to_end_host_call(eng, L, calls=3):
+    """What a host pays that only swaps the link line: ONE BGC_SourceSink of cfg2 (100 000 columns x 60 levels, every
+    diagnostic the reference's types carry) on pageable HOST arrays in the reference's level-fastest layout, staged over PCIe
+    by the library (OBGC_MEM_HOST, the path of the Fortran drop-in modules).  Wall time of the call, cold pH; never `value`."""
+    import numpy as np
+    from ocean_bgc_amd import synth
+    nc, nz, _ = CONFIGS["cfg2"]
+    syn = synth.generate(nc, nz)
+    tr = synth.bgc_tracer_array(syn)
+    tend = np.zeros_like(tr)
+    ph = np.zeros((2, nc, nz))
+    diag = {}
+    for nm in L.BGC_DIAG_KC:
+        if nm not in L.BGC_DIAG_KC_UNTOUCHED:
+            diag[nm] = np.zeros((nc, nz))
+    for nm in L.BGC_DIAG_KCA:
+        diag[nm] = np.zeros((4, nc, nz))
+    for nm in L.BGC_DIAG_CA:
+        diag[nm] = np.zeros((4, nc))
+    for nm in L.BGC_DIAG_C:
+        diag[nm] = np.zeros((nc,))
+    kmax = np.asarray(syn["kmax"], dtype=np.int32)
+    cells = int(np.minimum(kmax, nz).clip(0).sum())
+    ts = []
+    for _ in range(calls):
+        ph[:] = 0.0
+        t0 = time.perf_counter()
+        eng.bgc_source_sink(nz, nc, L.OBGC_LAYOUT_KFAST, tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"],
+                            kmax, syn["fesed"], syn["dust"], syn["sw"], tend, ph[0], ph[1], diag, True)
+        ts.append(time.perf_counter() - t0)
+    best = min(ts[1:]) if len(ts) > 1 else ts[0]      # the first call also grows the staging arena
+    up = sum(a.nbytes for a in (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["fesed"], ph))
+    down = tend.nbytes + ph.nbytes + sum(v.nbytes for v in diag.values())
+    return {"workload": "cfg2: one BGC_SourceSink call on pageable host arrays, reference layout, every diagnostic, cold pH "
+                        "(library stages over PCIe; Fortran drop-in path)",
+            "ms_per_call": best * 1e3, "value": 30 * cells / best, "unit": "updates/s", "calls": calls,
+            "bytes_up": up, "bytes_down": down, "link_GBps": (up + down) / best / 1e9,
+            "note": "PCIe-inclusive; for comparison with other_workloads.cfg2 (the same call on resident arrays); never the headline"}
+
+
 def roofline_of(w, eng, args, ROOT):
     """The dominant kernel of the step = the longest single launch."""
     import numpy as np
@@ -458,13 +502,28 @@ def free_port():
     return port
 
 
+def count_gpus_without_hip():
+    """GPUs the ranks will see, counted without loading a GPU runtime in THIS process: the visibility variables if set, else
+    a short-lived child process asks torch (the kernel driver's topology files list every GPU of the host, also those a
+    container cannot open, so they are no substitute)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             text=True, timeout=600).stdout.strip().splitlines()
+        return int(out[-1]) if out else 0
+    except Exception:
+        return 0
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's line.
-    The parent never touches a GPU: torch.cuda.device_count() only counts."""
+    The parent never touches a GPU and loads no GPU runtime (count_gpus_without_hip)."""
     n = args.gpus
     share = os.environ.get("OBGC_BENCH_SHARE_GPU", "0") == "1"
-    import torch
-    have = torch.cuda.device_count()
+    have = count_gpus_without_hip()
     if have < 1 or (have < n and not share):
         sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible\n" % (n, have))
         return 2
@@ -520,10 +579,17 @@ def main():
         raise SystemExit("--gpus must be >= 1")
 
     env_world = os.environ.get("WORLD_SIZE")
+    # OBGC_BENCH_FORCE_DIST=1: a one-GPU run goes through everything an N-GPU rank does -- the RCCL process group bound to
+    # its device, the barriers, the device all-reduces -- so that this code has run before a multi-GPU node meets it
+    force_dist = os.environ.get("OBGC_BENCH_FORCE_DIST", "0") == "1"
     if env_world is None:
         if args.gpus > 1:
             raise SystemExit(launch_ranks(args))
         world, rank, local_rank = 1, 0, 0
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     else:
         world = int(env_world)
         rank = int(os.environ.get("RANK", "0"))
@@ -550,7 +616,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     red_dev = dev
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
@@ -577,7 +643,7 @@ def main():
         torch.cuda.synchronize()
 
     elapsed = w.timed(args.steps, args.warmup, barrier)
-    elapsed, updates_all = reduce_results(dist, elapsed, w.updates_per_step, red_dev)
+    elapsed, updates_all, fastest = reduce_results(dist, elapsed, w.updates_per_step, red_dev)
     value = updates_all * args.steps / elapsed
 
     if rank == 0:
@@ -590,13 +656,18 @@ def main():
                           "columns_per_s": updates_all / w.updates_per_step * ncol * args.steps / elapsed if w.updates_per_step else 0.0,
                           "cells_per_s": updates_all / w.per_cell * args.steps / elapsed},
                "roofline": roofline_of(w, eng, args, ROOT)}
+        if dist is not None:      # a slow GPU of the node shows here, not as a scaling loss of the path
+            out["ranks"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                            "ms_per_step_slowest": elapsed / args.steps * 1e3, "ms_per_step_fastest": fastest / args.steps * 1e3}
         if world == 1 and not args.no_extras and not args.columns:
             del w
             torch.cuda.empty_cache()
             extras = {}
             for key, (name, ph, st, dg) in {"headline_warm_ph": (args.config, "warm" if args.ph == "cold" else "cold", 5, diag_on),
                                             "headline_other_diag_mode": (args.config, args.ph, 5, not diag_on),
-                                            "cfg2": ("cfg2", "cold", 10, diag_on), "cfg3": ("cfg3", "cold", 5, diag_on)}.items():
+                                            "cfg2": ("cfg2", "cold", 10, diag_on), "cfg3": ("cfg3", "cold", 5, diag_on),
+                                            # one GPU's share of cfg5 (8 M columns over 8 GPUs): every routine of the path
+                                            "cfg5_share_1gpu": ("cfg5", "cold", 4, diag_on)}.items():
                 if not key.startswith("headline") and name == args.config:
                     continue
                 try:
@@ -604,6 +675,10 @@ def main():
                 except Exception as exc:      # never lose the headline over an extra
                     extras[key] = {"failed": repr(exc)}
             out["other_workloads"] = extras
+            try:
+                out["end_to_end"] = end_to_end_host_call(eng, L)
+            except Exception as exc:
+                out["end_to_end"] = {"failed": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(nz, modules)

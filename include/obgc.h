@@ -272,8 +272,10 @@ typedef struct {
 
 int obgc_dms_source_sink(obgc_handle *h, const obgc_dms_source_sink_args *a);
 
-/* obgc_dms_source_sink for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments, same kernels and the same
+/* obgc_dms_source_sink for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code under HIP graph capture -- which additionally needs a handle created with OBGC_ASYNC, since a
+ * synchronous handle ends every call with a stream synchronisation, and captures obgc_stream(h)).  NO counterpart in
+ * the reference.  Same arguments, same kernels and the same
  * bits as obgc_dms_source_sink, but the three-plane hand-off of the light pass lives in a fixed device array of the
  * library instead of the handle's growing arena, so the call performs no hipMalloc / hipFree:
  *   - DEVICE pointers in the native COLFAST layout only (anything else: OBGC_ERR_UNSUPPORTED);

@@ -119,8 +119,9 @@ bool grid_ok(const obgc_grid& g) {
   return true;
 }
 
-// The column-block layout is served by the column-block kernel with the carbonate solve inside: one launch and the
-// column integrals of the production profiles, which read the caller's own photoC / photoC_NO3 / CaCO3_form / bSi_form.
+// The column-block layout is served by the column-block kernel (the carbonate solve inside it or in the carbonate kernel
+// beside it, as for the native layout) and the column integrals of the production profiles, which read the caller's own
+// photoC / photoC_NO3 / CaCO3_form / bSi_form.
 int tiled_ok(obgc_handle* h, const obgc_bgc_diag* d, const char* who) {
   if (!h->column)
     return fail(h, OBGC_ERR_UNSUPPORTED, std::string(who) + ": the TILED layout needs the column-block kernel (OBGC_COLUMN_KERNEL=0 is set)");
@@ -412,8 +413,11 @@ namespace {
 // `column`: the column-block kernel keeps the light and the hand-off on the chip; only the chlorophyll profile of the 100 m
 // integral goes through memory
 // whether the column-block kernel solves the carbonate system in its own wavefronts (schedule 3) for this view
-bool column_fuses(const obgc_handle* h, const GridView& kv, bool have_diag) {
-  if (kv.tiled) return true;   // one launch, no scratch planes: nothing of the engine's own lives in the caller's index space
+bool column_fuses(const obgc_handle* h, const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat) {
+  const bool have_diag = diag != nullptr;
+  // column blocks: the engine keeps nothing of its own in the caller's index space, so the saturation-horizon kernel can only
+  // run beside the column kernel on the caller's own CO3 / saturation arrays; without them the search runs inside the kernel
+  if (kv.tiled && want_zsat && !(diag->CO3 && diag->co3_sat_calc && diag->co3_sat_arag)) return true;
   const bool large = (long long)kv.nlev * kv.ncol > 10000000LL;
   return h->sched == 2 || (h->sched < 0 && large && have_diag);
 }
@@ -423,7 +427,7 @@ size_t bgc_scratch_bytes(const obgc_handle* h, const GridView& kv, const obgc_bg
   const size_t kc1 = span_kc(kv, 1);
   size_t bytes = 0;
   // (the column-block kernel with the carbonate solve inside searches the saturation horizons itself)
-  if (want_zsat && !(column && column_fuses(h, kv, diag != nullptr))) {
+  if (want_zsat && !(column && column_fuses(h, kv, diag, want_zsat))) {
     if (!diag->CO3) bytes += align_up(kc1);
     if (!diag->co3_sat_calc) bytes += align_up(kc1);
     if (!diag->co3_sat_arag) bytes += align_up(kc1);
@@ -450,7 +454,7 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
     h->arena_used += align_up(bytes);
     return p;
   };
-  if (want_zsat && !(column && column_fuses(h, kv, K.have_diag != 0))) {
+  if (want_zsat && !(column && column_fuses(h, kv, K.have_diag ? &K.diag : nullptr, want_zsat))) {
     K.co3_out = K.diag.CO3 ? K.diag.CO3 : carve(kc1);
     K.sat_calc_out = K.diag.co3_sat_calc ? K.diag.co3_sat_calc : carve(kc1);
     K.sat_arag_out = K.diag.co3_sat_arag ? K.diag.co3_sat_arag : carve(kc1);
@@ -492,7 +496,7 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
 //     this form is one launch plus its column scans and leaves s_aux idle.
 // OBGC_SCHED = 0 forces schedule 4, 1 starts the carbonate kernel when the column kernel ends, 2 forces schedule 3.
 int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const FusedDmArgs* F) {
-  const int fuse = column_fuses(h, K.g, K.have_diag != 0) ? 1 : 0;
+  const int fuse = column_fuses(h, K.g, K.have_diag ? &K.diag : nullptr, want_zsat) ? 1 : 0;
   h->last_sched = fuse ? 3 : 4;
   FusedParams fp;
   fp.dms = h->dms;

@@ -1,5 +1,7 @@
 // obgc_dms_source_sink_noalloc: DMS_SourceSink (DMS_mod.F90:156-770) for callers that cannot allocate device memory
-// -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+// -- tight serving loops, harnesses that forbid hipMalloc, code under HIP graph capture (there the handle must have been
+// created with OBGC_ASYNC, because a synchronous handle ends the call with a stream synchronisation, which a capturing
+// stream refuses, and the stream to capture is obgc_stream(h); no test of this library captures a graph).
 //
 // obgc_dms_source_sink keeps the hand-off of its light pass (exp(-KPARdz), KPARdz and the PAR entering each level: three
 // fp64 planes in the caller's index space) in the handle's arena, which it grows with hipMalloc on demand.  Here the same
@@ -11,8 +13,10 @@
 //   * every GPU the library runs on holds its own copy of the array (3 x 8 MiB) until the process ends;
 //   * every call on a GPU uses that GPU's array: calls that overlap in time on one GPU (two handles, OBGC_ASYNC) race;
 //   * the array keeps the last call's contents.  Nothing in it has to start at zero: the attenuation kernel writes every
-//     active cell of the first two planes before the scan reads them, the scan writes every active cell of the third
-//     before the cell kernel reads it, and cells below the sea floor are never read.
+//     active cell of the first two planes before the scan reads them and the scan writes every active cell of the third
+//     before the cell kernel reads it.  Cells below the sea floor ARE read by the cell kernel (one unconditional load
+//     batch per lane, inside the call's span) and their values discarded: whatever an earlier call left there never
+//     reaches an output.
 #include <mutex>
 
 #include "obgc_handle.h"
@@ -67,10 +71,13 @@ extern "C" int obgc_dms_source_sink_noalloc(obgc_handle* h, const obgc_dms_sourc
     return fail(h, OBGC_ERR_UNSUPPORTED,
                 "obgc_dms_source_sink_noalloc: " + std::to_string(span) + " (k,column) elements per plane exceed the fixed scratch of " +
                     std::to_string(kMaxCells) + "; use obgc_dms_source_sink");
-  if (h->device < 0 || h->device >= kMaxDevices || !g_scratch[h->device])
-    return fail(h, OBGC_ERR_HIP, "obgc_dms_source_sink_noalloc: the scratch array was not resolved on this device");
+  double* base = nullptr;
+  if (h->device >= 0 && h->device < kMaxDevices) {
+    std::lock_guard<std::mutex> lk(g_mu);   // obgc_create on another thread may be resolving another device's entry
+    base = g_scratch[h->device];
+  }
+  if (!base) return fail(h, OBGC_ERR_HIP, "obgc_dms_source_sink_noalloc: the scratch array was not resolved on this device");
   HIP_TRY(h, hipSetDevice(h->device));
-  double* base = g_scratch[h->device];
   h->timed_valid = false;
   DmsKernelArgs K = {};
   K.g = v;

@@ -39,6 +39,9 @@ class TileArena:
         self.torch, self.ncol, self.nlev, self.nrows = torch, int(ncol), int(nlev), int(nrows)
         self.nblk = (self.ncol + 63) // 64
         self.buf = torch.zeros((self.nblk, self.nlev, self.nrows, 64), dtype=torch.float64, device=device)
+        # the zero fill runs on torch's stream and the engine's streams do not order against it (include/obgc.h, "Stream
+        # ordering"): it must have finished before a library call writes into the arena
+        torch.cuda.synchronize(device)
         self.used = 0
 
     @property

@@ -13,7 +13,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 
 def _env(**kw):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "OBGC_BENCH_SHARE_GPU")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "OBGC_BENCH_SHARE_GPU", "OBGC_BENCH_FORCE_DIST")}
     env.update(kw)
     return env
 
@@ -56,3 +56,23 @@ def test_two_self_launched_ranks_share_the_one_gpu():
     rs = json.loads([ln for ln in st.stdout.splitlines() if ln.startswith("{")][-1])
     assert rs["n_gpus"] == 2 and rs["scaling"] == "strong"
     assert rs["config"]["updates_per_step_all_gpus"] == r1["config"]["updates_per_step_all_gpus"]
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_rccl_process_group():
+    """OBGC_BENCH_FORCE_DIST=1: a one-GPU run takes the code of an N-GPU rank -- init_process_group("nccl", device_id=...), the
+    barriers and the device all-reduces of the wall time and the work -- so that a multi-GPU node is not its first run."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    cmd = [sys.executable, BENCH, "--gpus", "1", "--config", "cfg4", "--columns", "20000", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=_env(OBGC_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["value"] > 0
+    assert r["ranks"]["backend"] == "nccl" and r["ranks"]["world_size"] == 1
+    assert r["ranks"]["ms_per_step_fastest"] == pytest.approx(r["ranks"]["ms_per_step_slowest"]) == pytest.approx(r["ms_per_step"])
+    plain = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    r0 = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "ranks" not in r0 and r0["config"]["updates_per_step_all_gpus"] == r["config"]["updates_per_step_all_gpus"]

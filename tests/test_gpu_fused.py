@@ -171,7 +171,7 @@ def test_fused_step_refuses_what_it_does_not_serve(pkg):
     f64 = dict(dtype=torch.float64, device="cuda")
     z = lambda *s: torch.zeros(s, **f64)
     km = torch.full((nc,), nz, dtype=torch.int32, device="cuda")
-    with pytest.raises(ObgcError, match="native column-fastest layout only"):
+    with pytest.raises(ObgcError, match="native column-fastest or column-block layout only"):
         eng.fused_step(nz, nc, L.OBGC_LAYOUT_KFAST, z(30, nc, nz), z(nc, nz), z(nc, nz), z(nc, nz), z(nc, nz), z(nc, nz), z(nc), km,
                        z(nc, nz), z(nc), z(nc), z(30, nc, nz), z(nc, nz), z(nc, nz), None, True, dms=z(nc, nz), dmsp=z(nc, nz), SST=z(nc),
                        dms_tend=z(nc, nz), dmsp_tend=z(nc, nz))

@@ -49,7 +49,7 @@ def test_bgc_source_sink_tiled_vs_reference_golden(engines, fixture):
     a = E.BGC_SourceSink(g["in.bgc_tracers"], *common, z, z, alt_co2_use_eco=True, diag_init=-7.0)
     rep = P.compare_bgc(a, P.golden_bgc(g, "bgc_cold"))
     assert rep.ok(), "\n".join(rep.fail[:12])
-    assert E.eng.last_schedule() == 3          # one launch: the column-block kernel with the carbonate solve inside
+    assert E.eng.last_schedule() in (3, 4)     # the column-block kernel, the carbonate solve inside or beside it
     for nm in F.BGC_DIAG_KC_UNTOUCHED:
         assert (a["kc"][nm] == -7.0).all(), nm
     below = np.arange(nz)[None, :] >= g["in.kmax"][:, None]
@@ -97,6 +97,38 @@ def test_tiled_equals_native_layout_bit_for_bit(engines, synth, nc, nz, diagnost
     # and the default arrangement of the native layout (carbonate kernel beside the column kernel below 10 M cells)
     dflt = engines["device_colfast"].BGC_SourceSink(*_args(syn, tr), z, z, diag_init=-3.0, diagnostics=diagnostics)
     _same(dflt, got["bgc"], "bgc, default schedule")
+
+
+def test_saturation_horizons_without_the_callers_co3_arrays(engines, synth):
+    """zsatcalc / zsatarag requested, CO3 / co3_sat_* not: the native layout keeps them in scratch planes for the
+    saturation-horizon kernel, the column-block layout has no scratch in the caller's index space and searches inside the
+    column kernel (schedule 3) -- the same bits either way."""
+    import torch
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import TileArena
+    nc, nz = 700, 60
+    syn = synth.generate(nc, nz, col0=31_000)
+    tr = synth.bgc_tracer_array(syn)
+    z = np.zeros((nc, nz))
+    want = engines["device_colfast"].BGC_SourceSink(*_args(syn, tr), z, z)
+    E = engines["device_tiled"].eng
+    A = TileArena(torch, "cuda:0", nc, nz, 30 + 6 + 30 + 2 + 16)
+    t = A.take(30).put(tr)
+    f = {nm: A.take(1, (nc, nz)).put(syn[nm]) for nm in ("temp", "salt", "zmid", "dz", "zbot", "fesed")}
+    tend, php, pha = A.take(30), A.take(1, (nc, nz)), A.take(1, (nc, nz))
+    diag = {nm: A.take(4) for nm in ("photoC", "photoC_NO3", "CaCO3_form", "bSi_form")}
+    for nm in ("zsatcalc", "zsatarag", "O2_ZMIN_DEPTH", "Jint_Ntot"):
+        diag[nm] = torch.full((nc,), -5.0, dtype=torch.float64, device="cuda")
+    cv = {nm: torch.from_numpy(np.ascontiguousarray(syn[nm])).cuda() for nm in ("lat", "dust", "sw")}
+    kmax = torch.from_numpy(np.asarray(syn["kmax"], dtype=np.int32)).cuda()
+    torch.cuda.synchronize()
+    E.bgc_source_sink(nz, nc, L.OBGC_LAYOUT_TILED, t, f["temp"], f["salt"], f["zmid"], f["dz"], f["zbot"], cv["lat"], kmax, f["fesed"],
+                      cv["dust"], cv["sw"], tend, php, pha, diag, True, ld=A.ld, plane=64)
+    assert E.last_schedule() == 3
+    assert np.array_equal(tend.get(), want["tend"]) and np.array_equal(php.get(), want["ph_prev"])
+    for nm in ("zsatcalc", "zsatarag", "O2_ZMIN_DEPTH", "Jint_Ntot"):
+        assert np.array_equal(diag[nm].cpu().numpy(), want["c"][nm]), nm
+    assert np.array_equal(diag["photoC"].get(), want["kca"]["photoC"])
 
 
 def test_surface_fluxes_update_and_means_in_the_tiled_layout(engines, synth):

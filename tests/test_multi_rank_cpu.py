@@ -30,7 +30,8 @@ def _worker(rank, world, port, ncol, nz, q):
     z = np.zeros((n, nz))
     res = O.bgc_source_sink(tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"],
                             syn["fesed"], syn["dust"], syn["sw"], z, z, diagnostics=False)
-    elapsed, updates = bench.reduce_results(dist, 1.0 + rank, 30 * int(syn["kmax"].sum()), torch.device("cpu"))
+    elapsed, updates, fastest = bench.reduce_results(dist, 1.0 + rank, 30 * int(syn["kmax"].sum()), torch.device("cpu"))
+    assert fastest == 1.0          # MIN over ranks: what shows a slow GPU next to the MAX
     q.put((rank, col0, n, res["tend"], res["ph_prev"], elapsed, updates, int(syn["kmax"].sum())))
     dist.barrier()
     dist.destroy_process_group()

@@ -79,3 +79,33 @@ def test_noalloc_entry_point_matches_the_allocating_one(pkg):
     want_t, _ = _run(torch, L, eng, b, False, False)
     got_t, _ = _run(torch, L, eng, b, True, False)
     assert torch.equal(got_t, want_t)
+
+
+def test_first_call_of_a_fresh_handle_allocates_nothing(pkg):
+    """A handle whose FIRST call is the no-alloc entry point: the arena of the allocating entry point was never grown, the
+    device's free memory does not move across the call, and the bits are those of the allocating entry point on another
+    handle."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    import torch
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    helper = Engine(0)                      # only generates the inputs (obgc_synth_fill needs a handle)
+    b = _batch(torch, L, helper, 60, 4_000, 77, 4_032)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    tend = torch.full((14, b["nz"], b["ld"]), -7.0, **f64)
+    d = {nm: torch.full((b["nz"], b["ld"]), -7.0, **f64) for nm in L.DMS_DIAG_KC}
+    # the HIP runtime uploads a kernel's code object on its first launch in a process: let ANOTHER handle pay for that
+    small = _batch(torch, L, helper, 60, 64, 0, 64)
+    _run(torch, L, helper, small, False, True)
+    fresh = Engine(0)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    fresh.dms_source_sink(b["nz"], b["nc"], L.OBGC_LAYOUT_COLFAST, b["dtr"], b["dz"], b["kmax"], b["sst"], b["sw"], tend, d,
+                          ld=b["ld"], plane=b["nz"] * b["ld"], noalloc=True)
+    fresh.sync()
+    assert torch.cuda.mem_get_info()[0] == free0, "the no-alloc entry point changed the device's free memory"
+    want_t, want_d = _run(torch, L, Engine(0), b, False, True)     # the allocating entry point, on a third handle, afterwards
+    assert torch.equal(tend, want_t)
+    for nm in L.DMS_DIAG_KC:
+        assert torch.equal(d[nm], want_d[nm]), nm
