@@ -433,9 +433,46 @@ int obgc_accumulate_arrays(obgc_handle *h, const obgc_grid *grid, int nplanes, c
                            double *const *mean_planes, int nvecs, const double *const *inst_vecs,
                            double *const *mean_vecs, double weight, int reset);
 
+/* --------------------------------- diagnostics selected by name
+ * NO reference counterpart.  The reference's host model reads a namelist of diagnostic names, averages those members over
+ * its output interval and writes them.  An obgc_diag_set does that next to the fields: it owns the instantaneous arrays and
+ * the running means of the SELECTED members only (names = the reference's members without the diag_ prefix, optionally
+ * qualified "bgc.", "dms." or "macros."; BGC_parms.F90:192-321, DMS_parms.F90:125-154, MACROS_parms.F90:105-113), gives the
+ * compute entry points pointer structs in which every other member is NULL -- so nothing else is written or even
+ * zero-filled -- and returns or writes the selected fields in the reference's X(k,column[,autotroph]) order.
+ *   - grid: DEVICE memory, COLFAST or TILED; the index space of the calls the structs are passed to.
+ *   - COLFAST: the set allocates everything (inst_rows = mean_rows = NULL).  TILED: the (k,column[,a]) members are rows of the
+ *     caller's arena -- obgc_diag_set_rows says how many -- starting at inst_rows / mean_rows (consecutive rows, in the order
+ *     of `names`, four for an autotroph-dimensioned member); (column[,a]) members are always the set's own.
+ *   - obgc_diag_set_bgc / _dms / _macros: the struct to pass as `diag` (NULL when no member of that module is selected).
+ *   - obgc_diag_set_accumulate: mean <- (reset ? 0 : mean) + weight * inst for every selected member (one launch a module).
+ *   - obgc_diag_set_download: one member (which = 0 the mean, 1 the instantaneous field) into a HOST array of
+ *     obgc_diag_set_elems values; obgc_diag_set_write: all of them into a file (format: csrc/obgc_io.cpp, "OBGCDIA1"),
+ *     read back by the host-only obgc_diag_file_* helpers.
+ *   - obgc_diag_names_read_text: the names of a parameter file's [diagnostics] section (`bgc = CO3, pH_3D` ...), as
+ *     `*count` NUL-terminated qualified names packed into `names` (a final empty string ends the list). */
+typedef struct obgc_diag_set obgc_diag_set;
+int obgc_diag_set_rows(int nnames, const char *const *names, int *rows, int *vectors, char *err, int errlen);
+int obgc_diag_set_create(obgc_handle *h, const obgc_grid *grid, int nnames, const char *const *names, double *inst_rows,
+                         double *mean_rows, obgc_diag_set **out);
+int obgc_diag_set_destroy(obgc_diag_set *s);
+int obgc_diag_set_count(const obgc_diag_set *s);
+const obgc_bgc_diag *obgc_diag_set_bgc(const obgc_diag_set *s);
+const obgc_dms_diag *obgc_diag_set_dms(const obgc_diag_set *s);
+const obgc_macros_diag *obgc_diag_set_macros(const obgc_diag_set *s);
+int obgc_diag_set_accumulate(obgc_diag_set *s, double weight, int reset);
+long long obgc_diag_set_elems(const obgc_diag_set *s, const char *name);
+int obgc_diag_set_download(obgc_diag_set *s, const char *name, int which, double *host, long long host_len);
+int obgc_diag_set_write(obgc_diag_set *s, const char *path, int which);
+int obgc_diag_names_read_text(const char *path, char *names, int nameslen, int *count, char *err, int errlen);
+int obgc_diag_file_info(const char *path, int *nlev, int *ncol, int *nrec, int *which);
+int obgc_diag_file_record(const char *path, int index, char *name, int namelen, int *module, int *kind, long long *nelem);
+int obgc_diag_file_read(const char *path, const char *name, double *out, long long len);
+
 /* ------------------------------- parameter files and restart state
  * Host-only helpers (no GPU needed).  The reference has no file format: its parameters are module variables.
- * Text format: sections [bgc], [autotroph N], [dms], [macros]; `name = value` with the reference's names; reals
+ * Text format: sections [bgc], [autotroph N], [dms], [macros] (and [diagnostics], see above: checked, otherwise ignored
+ * here); `name = value` with the reference's names; reals
  * are written as C99 hex floats (exact round trip), read as decimal or hex, always in the "C" locale.  Reading only
  * overrides the listed keys, so initialise the structs first (obgc_*_params_init); unknown keys are errors (message
  * in `err`).  Any of the three struct pointers may be NULL (section skipped on write, parsed but ignored on read).

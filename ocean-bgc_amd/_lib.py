@@ -206,6 +206,22 @@ PROTOTYPES = {
     "obgc_block_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "obgc_block_destroy": (C.c_int, [C.c_void_p]),
     "obgc_block_step": (C.c_int, [C.c_void_p, C.POINTER(BlockStepArgs)]),
+    "obgc_diag_set_rows": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "obgc_diag_set_create": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_int, C.POINTER(C.c_char_p), _dptr, _dptr, C.POINTER(C.c_void_p)]),
+    "obgc_diag_set_destroy": (C.c_int, [C.c_void_p]),
+    "obgc_diag_set_count": (C.c_int, [C.c_void_p]),
+    "obgc_diag_set_bgc": (C.POINTER(BgcDiag), [C.c_void_p]),
+    "obgc_diag_set_dms": (C.POINTER(DmsDiag), [C.c_void_p]),
+    "obgc_diag_set_macros": (C.POINTER(MacrosDiag), [C.c_void_p]),
+    "obgc_diag_set_accumulate": (C.c_int, [C.c_void_p, C.c_double, C.c_int]),
+    "obgc_diag_set_elems": (C.c_longlong, [C.c_void_p, C.c_char_p]),
+    "obgc_diag_set_download": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _dptr, C.c_longlong]),
+    "obgc_diag_set_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "obgc_diag_names_read_text": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "obgc_diag_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "obgc_diag_file_record": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_longlong)]),
+    "obgc_diag_file_read": (C.c_int, [C.c_char_p, C.c_char_p, _dptr, C.c_longlong]),
     "obgc_synth_fill": (C.c_int, [C.c_void_p, C.POINTER(SynthArgs)]),
     "obgc_synth_fill_extra": (C.c_int, [C.c_void_p, C.POINTER(SynthExtraArgs)]),
 }

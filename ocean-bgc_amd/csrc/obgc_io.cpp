@@ -10,6 +10,15 @@
 // sections are errors, not warnings.  The per-autotroph tracer slots (Chl_ind, C_ind, Fe_ind, Si_ind, CaCO3_ind) are
 // derived quantities (BGC_mod.F90:271-321): they are written for the reader's information and re-derived after a read.
 //
+// A [diagnostics] section selects diagnostics by the reference's member names (BGC_parms.F90:192-321, DMS_parms.F90:125-154,
+// MACROS_parms.F90:105-113; the diag_ prefix is optional): `bgc = CO3, pH_3D, photoC`, `dms = ...`, `macros = ...`; keys may
+// repeat.  obgc_params_read_text checks the names and otherwise ignores the section; obgc_diag_names_read_text returns them.
+//
+// Diagnostics file (written by obgc_diag_set_write): little-endian binary, 64-byte header
+//   char magic[8] = "OBGCDIA1"; int32 nlev, ncol, nrec, which (0 means, 1 instantaneous); int32 reserved[10];
+// then nrec records: a 64-byte record header { char name[40] ("bgc.CO3"); int32 module, kind, planes, reserved; int64 nelem }
+// followed by nelem fp64 values in the reference's order X(k,column[,autotroph]) resp. X(column[,autotroph]).
+//
 // Restart file: little-endian binary, 64-byte header
 //   char magic[8] = "OBGCRST1"; int32 nlev, ncol; int32 order; int32 reserved[11];
 // followed by four dense fp64 arrays: PH_PREV_3D(nlev,ncol), PH_PREV_ALT_CO2_3D(nlev,ncol), surface_pH(ncol),
@@ -105,6 +114,51 @@ bool set_macros(obgc_macros_params* p, const std::string& k, const std::string& 
   return false;
 }
 
+// module (0 BGC, 1 DMS, 2 MACROS) of a diagnostic name, -1 if there is none; `mod` restricts the search
+int diag_module(const std::string& mod, std::string nm) {
+  if (nm.rfind("diag_", 0) == 0) nm = nm.substr(5);
+  int found = -1, hits = 0;
+#define X(n) if ((mod.empty() || mod == "bgc") && nm == #n) { found = 0; ++hits; }
+  OBGC_BGC_DIAG_KC(X) OBGC_BGC_DIAG_KCA(X) OBGC_BGC_DIAG_CA(X) OBGC_BGC_DIAG_C(X)
+#undef X
+#define X(n) if ((mod.empty() || mod == "dms") && nm == #n) { found = 1; ++hits; }
+  OBGC_DMS_DIAG_KC(X)
+#undef X
+#define X(n) if ((mod.empty() || mod == "macros") && nm == #n) { found = 2; ++hits; }
+  OBGC_MACROS_DIAG_KC(X)
+#undef X
+  return hits == 1 ? found : -1;
+}
+
+// `bgc = a, b, c` of a [diagnostics] section -> "bgc.a", "bgc.b", ...; false on an unknown name
+bool diag_list(const std::string& mod, const std::string& v, std::vector<std::string>* out, std::string& bad) {
+  if (mod != "bgc" && mod != "dms" && mod != "macros") { bad = mod; return false; }
+  size_t pos = 0;
+  while (pos <= v.size()) {
+    size_t comma = v.find(',', pos);
+    if (comma == std::string::npos) comma = v.size();
+    std::string nm = trim(v.substr(pos, comma - pos));
+    pos = comma + 1;
+    if (nm.empty()) continue;
+    if (nm.rfind("diag_", 0) == 0) nm = nm.substr(5);
+    if (diag_module(mod, nm) < 0) { bad = nm; return false; }
+    if (out) out->push_back(mod + "." + nm);
+  }
+  return true;
+}
+
+struct DiagFileHeader {
+  char magic[8];
+  int32_t nlev, ncol, nrec, which;
+  int32_t reserved[10];
+};
+struct DiagRecordHeader {
+  char name[40];
+  int32_t module, kind, planes, reserved;
+  int64_t nelem;
+};
+static_assert(sizeof(DiagFileHeader) == 64 && sizeof(DiagRecordHeader) == 64, "diagnostics file headers are 64 bytes");
+
 struct RestartHeader {
   char magic[8];
   int32_t nlev, ncol;
@@ -160,7 +214,7 @@ extern "C" int obgc_params_read_text(const char* path, obgc_bgc_params* bgc, obg
   if (!path) return OBGC_ERR_INVALID;
   std::ifstream f(path);
   if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return OBGC_ERR_INVALID; }
-  enum { NONE, BGC, AUTO, DMS, MACROS } sec = NONE;
+  enum { NONE, BGC, AUTO, DMS, MACROS, DIAGS } sec = NONE;
   int autotroph = 0, lineno = 0;
   int rc = OBGC_OK;
   std::string line;
@@ -180,6 +234,7 @@ extern "C" int obgc_params_read_text(const char* path, obgc_bgc_params* bgc, obg
       if (name == "bgc") sec = BGC;
       else if (name == "dms") sec = DMS;
       else if (name == "macros") sec = MACROS;
+      else if (name == "diagnostics") sec = DIAGS;
       else if (name.rfind("autotroph", 0) == 0 && parse_int(trim(name.substr(9)), autotroph) && autotroph >= 1 &&
                autotroph <= OBGC_AUTOTROPH_CNT) sec = AUTO;
       else bad("unknown section [" + name + "]");
@@ -194,6 +249,7 @@ extern "C" int obgc_params_read_text(const char* path, obgc_bgc_params* bgc, obg
       case AUTO: ok = !bgc || set_autotroph(&bgc->autotrophs[autotroph - 1], k, v); break;
       case DMS: ok = !dms || set_dms(dms, k, v); break;
       case MACROS: ok = !macros || set_macros(macros, k, v); break;
+      case DIAGS: { std::string which; ok = diag_list(k, v, nullptr, which); } break;
       case NONE: bad("key before any section"); continue;
     }
     if (!ok) bad("unknown key or malformed value: " + k + " = " + v);
@@ -323,4 +379,102 @@ extern "C" int obgc_partition_columns(const int* kmax, long long ncol, int npart
     bounds[p] = c;
   }
   return OBGC_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics: names from a parameter file, files
+extern "C" int obgc_diag_names_read_text(const char* path, char* names, int nameslen, int* count, char* err, int errlen) {
+  if (!path || !count || (nameslen > 0 && !names)) return OBGC_ERR_INVALID;
+  std::ifstream f(path);
+  if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return OBGC_ERR_INVALID; }
+  std::vector<std::string> out;
+  bool in_sec = false;
+  int lineno = 0;
+  std::string line;
+  while (std::getline(f, line)) {
+    ++lineno;
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.erase(hash);
+    line = trim(line);
+    if (line.empty()) continue;
+    if (line.front() == '[') { in_sec = trim(line.substr(1, line.size() > 1 ? line.size() - 2 : 0)) == "diagnostics"; continue; }
+    if (!in_sec) continue;
+    const size_t eq = line.find('=');
+    std::string bad;
+    if (eq == std::string::npos || !diag_list(trim(line.substr(0, eq)), trim(line.substr(eq + 1)), &out, bad)) {
+      set_err(err, errlen, std::string(path) + ":" + std::to_string(lineno) + ": unknown diagnostic or module: " + bad);
+      return OBGC_ERR_INVALID;
+    }
+  }
+  size_t need = 0;
+  for (const std::string& n : out) need += n.size() + 1;
+  *count = (int)out.size();
+  if ((size_t)(nameslen > 0 ? nameslen : 0) < need + 1) {
+    set_err(err, errlen, "name buffer too small: " + std::to_string(need + 1) + " bytes needed");
+    return nameslen > 0 ? OBGC_ERR_INVALID : OBGC_OK;      // nameslen = 0: only counting
+  }
+  char* p = names;
+  for (const std::string& n : out) { std::memcpy(p, n.c_str(), n.size() + 1); p += n.size() + 1; }
+  *p = '\0';
+  return OBGC_OK;
+}
+
+extern "C" int obgc_diag_file_info(const char* path, int* nlev, int* ncol, int* nrec, int* which) {
+  if (!path) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return OBGC_ERR_INVALID;
+  DiagFileHeader h;
+  const bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "OBGCDIA1", 8) == 0 && h.nlev >= 1 && h.ncol >= 0 && h.nrec >= 0;
+  std::fclose(f);
+  if (!ok) return OBGC_ERR_INVALID;
+  if (nlev) *nlev = h.nlev;
+  if (ncol) *ncol = h.ncol;
+  if (nrec) *nrec = h.nrec;
+  if (which) *which = h.which;
+  return OBGC_OK;
+}
+
+namespace {
+// positions the file at the data of record `index` (name == NULL) or of the record called `name`; fills `rh`
+bool seek_record(FILE* f, int index, const char* name, DiagRecordHeader& rh) {
+  DiagFileHeader h;
+  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "OBGCDIA1", 8) != 0) return false;
+  for (int i = 0; i < h.nrec; ++i) {
+    if (std::fread(&rh, sizeof rh, 1, f) != 1 || rh.nelem < 0) return false;
+    rh.name[sizeof rh.name - 1] = '\0';
+    if (name ? std::strcmp(rh.name, name) == 0 : i == index) return true;
+    if (std::fseek(f, (long)(rh.nelem * (int64_t)sizeof(double)), SEEK_CUR) != 0) return false;
+  }
+  return false;
+}
+}  // namespace
+
+extern "C" int obgc_diag_file_record(const char* path, int index, char* name, int namelen, int* module, int* kind, long long* nelem) {
+  if (!path || index < 0) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return OBGC_ERR_INVALID;
+  DiagRecordHeader rh;
+  const bool ok = seek_record(f, index, nullptr, rh);
+  std::fclose(f);
+  if (!ok) return OBGC_ERR_INVALID;
+  if (name && namelen > 0) std::snprintf(name, (size_t)namelen, "%s", rh.name);
+  if (module) *module = rh.module;
+  if (kind) *kind = rh.kind;
+  if (nelem) *nelem = rh.nelem;
+  return OBGC_OK;
+}
+
+extern "C" int obgc_diag_file_read(const char* path, const char* name, double* out, long long len) {
+  if (!path || !name || !out) return OBGC_ERR_INVALID;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return OBGC_ERR_INVALID;
+  DiagRecordHeader rh;
+  std::string full = name;
+  if (full.find('.') == std::string::npos) {           // a bare member name: the module follows from it
+    const int m = diag_module("", full);
+    if (m >= 0) full = std::string(m == 0 ? "bgc." : (m == 1 ? "dms." : "macros.")) + (full.rfind("diag_", 0) == 0 ? full.substr(5) : full);
+  }
+  bool ok = seek_record(f, -1, full.c_str(), rh) && rh.nelem == len;
+  ok = ok && std::fread(out, sizeof(double), (size_t)len, f) == (size_t)len;
+  std::fclose(f);
+  return ok ? OBGC_OK : OBGC_ERR_INVALID;
 }

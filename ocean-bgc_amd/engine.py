@@ -232,7 +232,9 @@ class Engine:
                         fesedflux=fesedflux, dust_flux_in=dust_flux_in, sw_flux=sw_flux, tend=tend, ph_prev=ph_prev,
                         ph_prev_alt=ph_prev_alt), ms)
         d = None
-        if diag is not None:
+        if isinstance(diag, C.POINTER(L.BgcDiag)):      # a DiagSet's struct (lives as long as the set)
+            a.diag = diag
+        elif diag is not None:
             d = L.BgcDiag()
             self._fill(d, L.BGC_DIAG_KC + L.BGC_DIAG_KCA + L.BGC_DIAG_CA + L.BGC_DIAG_C, diag, ms)
             a.diag = C.pointer(d)
@@ -258,12 +260,16 @@ class Engine:
             raise ObgcError("fused_step: unknown arrays %s" % sorted(bad))
         self._fill(a, [n for n in self.FUSED_EXTRA if own.get(n) is not None], own, ms)
         keep = [d_bgc]
-        if dms_diag is not None:
+        if isinstance(dms_diag, C.POINTER(L.DmsDiag)):
+            a.dms_diag = dms_diag
+        elif dms_diag is not None:
             d = L.DmsDiag()
             self._fill(d, L.DMS_DIAG_KC, dms_diag, ms)
             a.dms_diag = C.pointer(d)
             keep.append(d)
-        if macros_diag is not None:
+        if isinstance(macros_diag, C.POINTER(L.MacrosDiag)):
+            a.macros_diag = macros_diag
+        elif macros_diag is not None:
             d = L.MacrosDiag()
             self._fill(d, L.MACROS_DIAG_KC, macros_diag, ms)
             a.macros_diag = C.pointer(d)
@@ -396,6 +402,10 @@ class Engine:
                                                     table(vecs, 0), table(vecs, 1), float(weight), 1 if reset else 0),
                     "obgc_accumulate_arrays")
 
+    def diag_set(self, nlev, ncol, names, layout=L.OBGC_LAYOUT_COLFAST, ld=0, plane=0, ldc=0, inst_rows=None, mean_rows=None):
+        """Diagnostics selected by the reference's member names (obgc_diag_set_*): see DiagSet."""
+        return DiagSet(self, nlev, ncol, names, layout, ld, plane, ldc, inst_rows, mean_rows)
+
     def synth_fill(self, nlev, ncol, col0, ld=0, plane=0, ind=None, tiled=False, **dev_arrays):
         """Fill device tensors (native COLFAST layout, or column blocks with tiled=True) with the synthetic workload."""
         a = L.SynthArgs()
@@ -428,3 +438,95 @@ class Engine:
                 raise ObgcError("synth_fill_extra needs device tensors")
             setattr(a, nm, p)
         self._check(self.lib.obgc_synth_fill_extra(self.h, C.byref(a)), "obgc_synth_fill_extra")
+
+
+def diag_names_from_file(path):
+    """The qualified names of a parameter file's [diagnostics] section (obgc_diag_names_read_text; host-only)."""
+    lib = L.load()
+    n = C.c_int(0)
+    err = C.create_string_buffer(512)
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib.obgc_diag_names_read_text(path.encode(), buf, len(buf), C.byref(n), err, len(err))
+    if rc != 0:
+        raise ObgcError("obgc_diag_names_read_text: %s" % err.value.decode())
+    return [x.decode() for x in buf.raw.split(b"\0")[:n.value]]
+
+
+def diag_file_read(path):
+    """-> (header dict, {qualified name: numpy array in the reference's order}) of a file written by DiagSet.write."""
+    lib = L.load()
+    nlev, ncol, nrec, which = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if lib.obgc_diag_file_info(path.encode(), C.byref(nlev), C.byref(ncol), C.byref(nrec), C.byref(which)) != 0:
+        raise ObgcError("not a diagnostics file: %s" % path)
+    out = {}
+    for i in range(nrec.value):
+        name = C.create_string_buffer(64)
+        mod, kind, nelem = C.c_int(), C.c_int(), C.c_longlong()
+        if lib.obgc_diag_file_record(path.encode(), i, name, len(name), C.byref(mod), C.byref(kind), C.byref(nelem)) != 0:
+            raise ObgcError("bad record %d in %s" % (i, path))
+        a = np.empty(nelem.value)
+        if lib.obgc_diag_file_read(path.encode(), name.value, a.ctypes.data, a.size) != 0:
+            raise ObgcError("cannot read %s from %s" % (name.value.decode(), path))
+        shape = {0: (ncol.value, nlev.value), 1: (4, ncol.value, nlev.value), 2: (4, ncol.value), 3: (ncol.value,)}[kind.value]
+        out[name.value.decode()] = a.reshape(shape)
+    return dict(nlev=nlev.value, ncol=ncol.value, nrec=nrec.value, which=which.value), out
+
+
+class DiagSet:
+    """A selection of diagnostics by name with its instantaneous arrays and running means on the device.
+    .bgc / .dms / .macros are what to pass as diag= / dms_diag= / macros_diag= to Engine.bgc_source_sink / fused_step."""
+
+    def __init__(self, eng, nlev, ncol, names, layout, ld, plane, ldc, inst_rows, mean_rows):
+        self.eng, self.lib = eng, eng.lib
+        self.nlev, self.ncol = nlev, ncol
+        self.grid = make_grid(nlev, ncol, layout, L.OBGC_MEM_DEVICE, ld, plane, ldc)
+        arr = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        s = C.c_void_p()
+        ir = _ptr(inst_rows)[0] if inst_rows is not None else None
+        mr = _ptr(mean_rows)[0] if mean_rows is not None else None
+        eng._check(self.lib.obgc_diag_set_create(eng.h, C.byref(self.grid), len(names), arr, ir, mr, C.byref(s)), "obgc_diag_set_create")
+        self.s = s
+        self.bgc = self.lib.obgc_diag_set_bgc(s) or None
+        self.dms = self.lib.obgc_diag_set_dms(s) or None
+        self.macros = self.lib.obgc_diag_set_macros(s) or None
+
+    @staticmethod
+    def rows(names):
+        lib = L.load()
+        arr = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        r, v = C.c_int(), C.c_int()
+        err = C.create_string_buffer(256)
+        if lib.obgc_diag_set_rows(len(names), arr, C.byref(r), C.byref(v), err, len(err)) != 0:
+            raise ObgcError(err.value.decode())
+        return r.value, v.value
+
+    def __len__(self):
+        return self.lib.obgc_diag_set_count(self.s)
+
+    def accumulate(self, weight, reset=False):
+        self.eng._check(self.lib.obgc_diag_set_accumulate(self.s, float(weight), 1 if reset else 0), "obgc_diag_set_accumulate")
+
+    def download(self, name, which="mean"):
+        n = self.lib.obgc_diag_set_elems(self.s, name.encode())
+        if n < 0:
+            raise ObgcError("%s is not in the selection" % name)
+        a = np.empty(n)
+        self.eng._check(self.lib.obgc_diag_set_download(self.s, name.encode(), 0 if which == "mean" else 1, a.ctypes.data, n),
+                        "obgc_diag_set_download")
+        kc = self.nlev * self.ncol
+        shape = {kc: (self.ncol, self.nlev), 4 * kc: (4, self.ncol, self.nlev), 4 * self.ncol: (4, self.ncol), self.ncol: (self.ncol,)}
+        return a.reshape(shape[n])
+
+    def write(self, path, which="mean"):
+        self.eng._check(self.lib.obgc_diag_set_write(self.s, path.encode(), 0 if which == "mean" else 1), "obgc_diag_set_write")
+
+    def close(self):
+        if getattr(self, "s", None):
+            self.lib.obgc_diag_set_destroy(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

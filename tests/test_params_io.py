@@ -156,3 +156,35 @@ def test_restart_file_in_the_native_layout_and_order_word(L, tmp_path):
     open(p1.decode(), "wb").write(bytes(raw))
     fl, fc = C.c_int(), C.c_int()
     assert lib.obgc_restart_read_header(p1, C.byref(fl), C.byref(fc)) == -1
+
+
+def test_diagnostics_section_names_and_file_helpers(L, tmp_path):
+    """[diagnostics] of a parameter file: names are checked by obgc_params_read_text and returned, qualified, by
+    obgc_diag_names_read_text; a diagnostics file laid out as csrc/obgc_io.cpp documents is read by the host-only helpers."""
+    import ctypes as C
+    import struct
+    import numpy as np
+    from ocean_bgc_amd.engine import DiagSet, ObgcError, diag_file_read, diag_names_from_file
+    lib = L.load()
+    p = str(tmp_path / "p.txt")
+    open(p, "w").write("[bgc]\nparm_Fe_bioavail = 0.5\n[diagnostics]\nbgc = CO3, diag_pH_3D , photoC\ndms = DMS_R_TOTAL\nbgc=Jint_Ctot\n")
+    assert diag_names_from_file(p) == ["bgc.CO3", "bgc.pH_3D", "bgc.photoC", "dms.DMS_R_TOTAL", "bgc.Jint_Ctot"]
+    b = L.BgcParams()
+    lib.obgc_bgc_params_init(C.byref(b), None, 273.15)
+    err = C.create_string_buffer(256)
+    assert lib.obgc_params_read_text(p.encode(), C.byref(b), None, None, err, 256) == 0 and b.parm_Fe_bioavail == 0.5
+    open(p, "w").write("[diagnostics]\nbgc = CO3, no_such_member\n")
+    assert lib.obgc_params_read_text(p.encode(), C.byref(b), None, None, err, 256) != 0 and b"no_such_member" in err.value
+    with pytest.raises(ObgcError, match="no_such_member"):
+        diag_names_from_file(p)
+    assert DiagSet.rows(["CO3", "photoC", "bgc.Jint_Ctot", "photoC_zint", "dms.DMS_R_TOTAL"]) == (6, 5)
+    with pytest.raises(ObgcError, match="unknown or ambiguous"):
+        DiagSet.rows(["macros.CO3"])
+    nz, nc = 3, 2
+    a = np.arange(24, dtype=np.float64).reshape(4, nc, nz)
+    path = str(tmp_path / "hand.obgcdia")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8s4i10i", b"OBGCDIA1", nz, nc, 1, 0, *([0] * 10)))
+        f.write(struct.pack("<40s4iq", b"bgc.photoC", 0, 1, 4, 0, a.size) + a.tobytes())
+    hdr, rec = diag_file_read(path)
+    assert hdr == dict(nlev=nz, ncol=nc, nrec=1, which=0) and np.array_equal(rec["bgc.photoC"], a)
