@@ -404,10 +404,18 @@ typedef struct {
   double *ecosysTracersTend;         /* (30, nVertLevels, nCells): += layerThickness * tendency (accumulate != 0) or = (0) */
   double *ecosysSurfaceFlux;         /* (30, nCells) out: netFlux * 0.01 */
   int accumulate;
+  /* Optional (NULL = not run): DMS and / or MACROS on the same cells in the same step.  The tracers the two modules share
+   * with BGC (DMS_mod.F90:471-482, MACROS_mod.F90:301-325) are taken from ecosysTracers; only their own tracers travel.
+   * The source-sink part then runs as ONE obgc_fused_step, and DMS_SurfaceFluxes follows BGC_SurfaceFluxes. */
+  const double *dmsTracers;          /* (2, nVertLevels, nCells): dms, dmsp, tracer index fastest */
+  double *dmsTracersTend;            /* (2, nVertLevels, nCells): += or = layerThickness * tendency, as ecosysTracersTend */
+  double *dmsSurfaceFlux;            /* (2, nCells) out: DMS_SurfaceFluxes netFlux(dms, dmsp) * 0.01 */
+  const double *macrosTracers;       /* (3, nVertLevels, nCells): prot, poly, lip */
+  double *macrosTracersTend;         /* (3, nVertLevels, nCells) */
 } obgc_block_step_args;
 
 /* one BGC_SurfaceFluxes + BGC_SourceSink over the whole block (tendencies only; PH_PREV_* and surface_pH* persist
- * inside the block) */
+ * inside the block); with dmsTracers / macrosTracers also DMS_SurfaceFluxes and the fused BGC + DMS + MACROS step */
 int obgc_block_step(obgc_block *b, const obgc_block_step_args *a);
 
 /* --------------------------------------- diagnostics kept on the device

@@ -137,7 +137,8 @@ class BlockStepArgs(C.Structure):
         "ecosysTracers", "layerThickness", "zMid", "temperature", "salinity", "maxLevelCell", "latCell", "shortWaveHeatFlux",
         "atmosphericPressure", "iceFraction", "windSpeedSquared10m", "atmosphericCO2", "atmosphericCO2_ALT_CO2", "dustFlux",
         "ironSedimentFlux", "depositionFlux", "riverFlux", "seaIceFlux", "ecosysTracersTend", "ecosysSurfaceFlux")] + \
-        [("accumulate", C.c_int)]
+        [("accumulate", C.c_int)] + \
+        [(n, _dptr) for n in ("dmsTracers", "dmsTracersTend", "dmsSurfaceFlux", "macrosTracers", "macrosTracersTend")]
 
 
 class SynthArgs(C.Structure):

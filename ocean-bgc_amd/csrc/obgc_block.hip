@@ -9,7 +9,7 @@
 #include <thread>
 #include <vector>
 
-#include "obgc_internal.h"
+#include "obgc_handle.h"
 
 struct obgc_block {
   obgc_handle* h = nullptr;
@@ -28,6 +28,11 @@ struct obgc_block {
   int chunks = 8, min_cells = 8192, threads = 1;   // OBGC_HOST_THREADS=0: downloads in line
   hipStream_t s_down = nullptr;
   hipEvent_t ev_done[kMaxChunks] = {};
+  // DMS / MACROS on the block (allocated by the first step that asks for them): own tracers and tendencies as five native
+  // planes (dms, dmsp, prot, poly, lip), a one-level 14-plane tracer array for DMS_SurfaceFluxes, its net flux, staging
+  char* pool2 = nullptr;
+  double *own = nullptr, *own_tend = nullptr, *dms_surf_tr = nullptr, *dms_net = nullptr;
+  double *m_own[2] = {nullptr, nullptr}, *m_own_tend[2] = {nullptr, nullptr}, *m_dms_sflux = nullptr;
 };
 
 namespace obgc {
@@ -115,6 +120,38 @@ __global__ __launch_bounds__(64) void block_pack_fields_kernel(PackArgs a) {
   a.sss[c] = a.s[(long long)c * a.nz];
 }
 
+// The same two for the few own tracers of DMS (2) and MACROS (3): one lane per (column, level), lanes along the columns.
+__global__ __launch_bounds__(256) void block_pack_small_kernel(const double* __restrict__ src, double* __restrict__ dst, int nz, int nc,
+                                                               long long ld, int ntr) {
+  const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (c >= nc) return;
+  for (int n = 0; n < ntr; ++n) dst[((long long)n * nz + k) * ld + c] = src[((long long)c * nz + k) * ntr + n];
+}
+
+__global__ __launch_bounds__(256) void block_unpack_small_kernel(const double* __restrict__ tend, const double* __restrict__ h_kc,
+                                                                 const int* __restrict__ kmax, double* __restrict__ out, int nz, int nc,
+                                                                 long long ld, int ntr, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (c >= nc) return;
+  const bool active = k < kmax[c];
+  const double hk = h_kc[(long long)c * nz + k];
+  for (int n = 0; n < ntr; ++n) {
+    const long long o = ((long long)c * nz + k) * ntr + n;
+    const double v = hk * tend[((long long)n * nz + k) * ld + c];
+    if (accumulate) { if (active) out[o] = out[o] + v; }
+    else out[o] = active ? v : 0.0;
+  }
+}
+
+// DMS surface flux out: (2, nCells) from the dms and dmsp rows of DMS_SurfaceFluxes' netFlux(column, 14)
+__global__ __launch_bounds__(256) void block_dms_sflux_kernel(const double* __restrict__ net, double* __restrict__ out, int nc, long long ld,
+                                                              int i_dms, int i_dmsp) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  out[2LL * c] = net[(long long)(i_dms - 1) * ld + c] * CM_TO_M;
+  out[2LL * c + 1] = net[(long long)(i_dmsp - 1) * ld + c] * CM_TO_M;
+}
+
 // (c, n) model flux arrays are already (column, tracer) column-fastest; surface flux out: (n, c) tracer-fastest
 __global__ __launch_bounds__(256) void block_sflux_kernel(const double* __restrict__ net, double* __restrict__ out, int nc, long long ld) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -181,11 +218,31 @@ extern "C" int obgc_block_destroy(obgc_block* b) {
   if (b->s_down) (void)hipStreamDestroy(b->s_down);
   for (hipEvent_t e : b->ev_done) if (e) (void)hipEventDestroy(e);
   (void)hipFree(b->pool);
+  if (b->pool2) (void)hipFree(b->pool2);
   delete b;
   return OBGC_OK;
 }
 
 namespace {
+
+// device room for DMS / MACROS on the block, on the first step that runs them
+int block_reserve_own(obgc_block* b) {
+  if (b->pool2) return OBGC_OK;
+  const size_t nc = (size_t)b->nc, kc = nc * (size_t)b->nz, d = sizeof(double), al = 256;
+  size_t total = 0;
+  std::vector<std::pair<void**, size_t>> slots;
+  auto want = [&](void** p, size_t bytes) { slots.push_back({p, total}); total += (bytes + al - 1) / al * al; };
+  want((void**)&b->own, 5 * kc * d); want((void**)&b->own_tend, 5 * kc * d);
+  want((void**)&b->dms_surf_tr, OBGC_DMS_NTRACER * nc * d); want((void**)&b->dms_net, OBGC_DMS_NTRACER * nc * d);
+  want((void**)&b->m_own[0], 2 * kc * d); want((void**)&b->m_own[1], 3 * kc * d);
+  want((void**)&b->m_own_tend[0], 2 * kc * d); want((void**)&b->m_own_tend[1], 3 * kc * d);
+  want((void**)&b->m_dms_sflux, 2 * nc * d);
+  if (hipMalloc((void**)&b->pool2, total) != hipSuccess) return OBGC_ERR_ALLOC;
+  for (auto& s : slots) *s.first = b->pool2 + s.second;
+  hipStream_t st = (hipStream_t)obgc_stream(b->h);
+  if (hipMemsetAsync(b->pool2, 0, total, st) != hipSuccess) return OBGC_ERR_HIP;
+  return OBGC_OK;
+}
 
 // cells [c0, c1) of the block: upload their slices, pack, BGC_SurfaceFluxes + BGC_SourceSink on the native arrays (a
 // column range of a column-fastest array is the same array with an offset and the block's row stride), unpack
@@ -200,7 +257,23 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
   UP(b->m_t + kc0, a->temperature + kc0, kcn * d) UP(b->m_s + kc0, a->salinity + kc0, kcn * d)
   UP(b->m_fesed + kc0, a->ironSedimentFlux + kc0, kcn * d)
   if (a->accumulate) UP(b->m_tend + NT * kc0, a->ecosysTracersTend + NT * kc0, NT * kcn * d)
+  const bool with_dms = a->dmsTracers != nullptr, with_macros = a->macrosTracers != nullptr;
+  if (with_dms) {
+    UP(b->m_own[0] + 2 * kc0, a->dmsTracers + 2 * kc0, 2 * kcn * d)
+    if (a->accumulate) UP(b->m_own_tend[0] + 2 * kc0, a->dmsTracersTend + 2 * kc0, 2 * kcn * d)
+  }
+  if (with_macros) {
+    UP(b->m_own[1] + 3 * kc0, a->macrosTracers + 3 * kc0, 3 * kcn * d)
+    if (a->accumulate) UP(b->m_own_tend[1] + 3 * kc0, a->macrosTracersTend + 3 * kc0, 3 * kcn * d)
+  }
 #undef UP
+  const long long plane = (long long)ncb * nz;
+  if (with_dms)
+    hipLaunchKernelGGL(block_pack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->m_own[0] + 2 * kc0, b->own + c0, nz, n,
+                       (long long)ncb, 2);
+  if (with_macros)
+    hipLaunchKernelGGL(block_pack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->m_own[1] + 3 * kc0, b->own + 2 * plane + c0,
+                       nz, n, (long long)ncb, 3);
   hipLaunchKernelGGL(block_pack_tracers_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->m_tr + NT * kc0, b->tracers + c0, nz, n,
                      (long long)ncb);
   PackArgs pa;
@@ -238,8 +311,45 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
   ss.dz = b->dz + c0; ss.zbot = b->zbot + c0;
   ss.lat = b->lat + c0; ss.kmax = b->kmax + c0; ss.fesedflux = b->fesed + c0; ss.dust_flux_in = b->dust + c0; ss.sw_flux = b->sw + c0;
   ss.tend = b->tend + c0; ss.ph_prev = b->php + c0; ss.ph_prev_alt = b->pha + c0; ss.diag = nullptr; ss.alt_co2_use_eco = 0;
-  rc = obgc_bgc_source_sink(b->h, &ss);
+  if (with_dms) {
+    // DMS_SurfaceFluxes reads the surface row of ONE tracer (DMS_mod.F90:834): a one-level 14-plane array holds it
+    const obgc_dms_params& dp = b->h->dms;
+    if (hipMemcpyAsync(b->dms_surf_tr + (size_t)(dp.ind[0] - 1) * ncb + c0, b->own + c0, (size_t)n * d, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return OBGC_ERR_HIP;
+    obgc_dms_surface_fluxes_args ds;
+    std::memset(&ds, 0, sizeof ds);
+    ds.grid = g; ds.grid.nlev = 1; ds.grid.plane = ncb;
+    ds.tracers = b->dms_surf_tr + c0;
+    ds.surfacePressure = b->patm + c0; ds.windSpeedSquared10m = b->wind + c0; ds.SST = b->sst + c0; ds.SSS = b->sss + c0;
+    ds.iceFraction = b->ice + c0; ds.netFlux = b->dms_net + c0; ds.lcalc_DMS_gas_flux = 1;
+    rc = obgc_dms_surface_fluxes(b->h, &ds);
+    if (rc != OBGC_OK) return rc;
+    hipLaunchKernelGGL(block_dms_sflux_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b->dms_net + c0, b->m_dms_sflux + 2 * (size_t)c0, n,
+                       (long long)ncb, dp.ind[0], dp.ind[1]);
+  }
+  if (with_dms || with_macros) {
+    obgc_fused_step_args fs;
+    std::memset(&fs, 0, sizeof fs);
+    fs.bgc = ss;
+    if (with_dms) {
+      fs.dms = b->own + c0; fs.dmsp = b->own + plane + c0; fs.SST = b->sst + c0;
+      fs.dms_tend = b->own_tend + c0; fs.dmsp_tend = b->own_tend + plane + c0;
+    }
+    if (with_macros) {
+      fs.prot = b->own + 2 * plane + c0; fs.poly = b->own + 3 * plane + c0; fs.lip = b->own + 4 * plane + c0;
+      fs.prot_tend = b->own_tend + 2 * plane + c0; fs.poly_tend = b->own_tend + 3 * plane + c0; fs.lip_tend = b->own_tend + 4 * plane + c0;
+    }
+    rc = obgc_fused_step(b->h, &fs);
+  } else {
+    rc = obgc_bgc_source_sink(b->h, &ss);
+  }
   if (rc != OBGC_OK) return rc;
+  if (with_dms)
+    hipLaunchKernelGGL(block_unpack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->own_tend + c0, b->m_h + kc0, b->kmax + c0,
+                       b->m_own_tend[0] + 2 * kc0, nz, n, (long long)ncb, 2, a->accumulate ? 1 : 0);
+  if (with_macros)
+    hipLaunchKernelGGL(block_unpack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->own_tend + 2 * plane + c0, b->m_h + kc0,
+                       b->kmax + c0, b->m_own_tend[1] + 3 * kc0, nz, n, (long long)ncb, 3, a->accumulate ? 1 : 0);
 
   hipLaunchKernelGGL(block_unpack_tend_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->tend + c0, b->m_h + kc0, b->kmax + c0,
                      b->m_tend + NT * kc0, nz, n, (long long)ncb, a->accumulate ? 1 : 0);
@@ -254,6 +364,13 @@ hipError_t block_download_range(obgc_block* b, const obgc_block_step_args* a, in
   if (e == hipSuccess)
     e = hipMemcpyAsync(a->ecosysSurfaceFlux + (size_t)NT * c0, b->m_sflux + (size_t)NT * c0, NT * (size_t)(c1 - c0) * d,
                        hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && a->dmsTracers) {
+    e = hipMemcpyAsync(a->dmsTracersTend + 2 * kc0, b->m_own_tend[0] + 2 * kc0, 2 * kcn * d, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(a->dmsSurfaceFlux + 2 * (size_t)c0, b->m_dms_sflux + 2 * (size_t)c0, 2 * (size_t)(c1 - c0) * d, hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess && a->macrosTracers)
+    e = hipMemcpyAsync(a->macrosTracersTend + 3 * kc0, b->m_own_tend[1] + 3 * kc0, 3 * kcn * d, hipMemcpyDeviceToHost, st);
   return e;
 }
 
@@ -269,10 +386,15 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
       !a->atmosphericCO2_ALT_CO2 || !a->dustFlux || !a->ironSedimentFlux || !a->depositionFlux || !a->riverFlux || !a->seaIceFlux ||
       !a->ecosysTracersTend || !a->ecosysSurfaceFlux)
     return OBGC_ERR_INVALID;
+  if ((a->dmsTracers && (!a->dmsTracersTend || !a->dmsSurfaceFlux)) || (a->macrosTracers && !a->macrosTracersTend)) return OBGC_ERR_INVALID;
   const int nc = b->nc;
   const size_t d = sizeof(double);
   const int device = handle_device(b->h);
   if (hipSetDevice(device) != hipSuccess) return OBGC_ERR_HIP;   // the calling thread's current device may be another GPU
+  if (a->dmsTracers || a->macrosTracers) {
+    const int rc2 = block_reserve_own(b);
+    if (rc2 != OBGC_OK) return rc2;
+  }
   hipStream_t st = (hipStream_t)obgc_stream(b->h);
   // per-cell arrays: small, whole block at once
 #define UP(dst, src, bytes) if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return OBGC_ERR_HIP;

@@ -246,3 +246,75 @@ def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, 
     active = (np.arange(nz)[None, :] < m["kmax"][:, None])[:, :, None]
     assert np.array_equal(acc, np.where(active, base + over, base))
     assert E.lib.obgc_block_destroy(blk) == 0 and E.lib.obgc_block_destroy(blk2) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_resident_block_with_dms_and_macros_in_the_fused_step(synth, oracle, pkg, monkeypatch, chunks):
+    """A host that runs all three packages on host arrays: obgc_block_step with the own tracers of DMS and MACROS -- the
+    source-sink part is ONE obgc_fused_step on the block, DMS_SurfaceFluxes follows BGC_SurfaceFluxes.  Same bits as the
+    block's BGC-only step plus the separate DMS / MACROS entry points fed the package-side arrays through the host path, and
+    inside the parity bars against the oracle; the accumulate switch covers all three tendency arrays."""
+    import ctypes as C
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    monkeypatch.setenv("OBGC_BLOCK_CHUNKS", str(chunks))
+    monkeypatch.setenv("OBGC_BLOCK_MIN_CELLS", "0")
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    from ocean_bgc_amd.modules import ColumnEngine
+    nc, nz = 640, 60
+    m, pk = mpas_block(synth, nc, nz, col0=120000)
+    syn = synth.generate(nc, nz, col0=120000)
+    dtr, mtr = synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)        # [14 | 8, c, k], shared slots = BGC tracers
+    own_d = np.ascontiguousarray(dtr[0:2].transpose(1, 2, 0))                      # (2, k, c) tracer-fastest
+    own_m = np.ascontiguousarray(mtr[0:3].transpose(1, 2, 0))
+    E = Engine(0)
+    blk, blk0 = C.c_void_p(), C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk)) == 0 and E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk0)) == 0
+
+    def step(block, tend, dtend, mtend, accumulate, with_own=True):
+        a, keep, sflux = block_args(L, m, nc, nz, tend, accumulate)
+        dsf = np.full((nc, 2), -9.0)
+        if with_own:
+            a.dmsTracers = own_d.ctypes.data_as(C.c_void_p); a.dmsTracersTend = dtend.ctypes.data_as(C.c_void_p)
+            a.dmsSurfaceFlux = dsf.ctypes.data_as(C.c_void_p)
+            a.macrosTracers = own_m.ctypes.data_as(C.c_void_p); a.macrosTracersTend = mtend.ctypes.data_as(C.c_void_p)
+        rc = E.lib.obgc_block_step(block, C.byref(a))
+        assert rc == 0, (rc, E.lib.obgc_last_error(E.h))
+        return sflux, dsf
+
+    tend, dtend, mtend = np.full((nc, nz, 30), 123.0), np.full((nc, nz, 2), 123.0), np.full((nc, nz, 3), 123.0)
+    sflux, dsf = step(blk, tend, dtend, mtend, False)
+    # BGC: the bits of the BGC-only block step
+    tend0 = np.full((nc, nz, 30), 123.0)
+    sflux0, _ = step(blk0, tend0, None, None, False, with_own=False)
+    assert np.array_equal(tend, tend0) and np.array_equal(sflux, sflux0)
+    # DMS / MACROS: the bits of the separate entry points on the package-side arrays (host path), thickness-weighted
+    H = ColumnEngine(0, path="host")
+    d = H.DMS_SourceSink(dtr, pk["dz"], pk["kmax"], pk["forcing"]["SST"], pk["sw"])
+    mm = H.MACROS_SourceSink(mtr, pk["kmax"])
+    active = (np.arange(nz)[None, :] < pk["kmax"][:, None])[:, :, None]
+    want_d = np.where(active, m["h"][:, :, None] * d["tend"][0:2].transpose(1, 2, 0), 0.0)
+    want_m = np.where(active, m["h"][:, :, None] * mm["tend"][0:3].transpose(1, 2, 0), 0.0)
+    assert np.array_equal(dtend, want_d) and np.array_equal(mtend, want_m)
+    frc = {k: np.array(v, dtype=np.float64) for k, v in pk["forcing"].items()}
+    ds = H.DMS_SurfaceFluxes(dtr, frc)
+    assert np.array_equal(dsf, ds["netFlux"][0:2].T * CM_TO_M)
+    # and the oracle, inside the bars
+    od = oracle.dms_source_sink(dtr, pk["dz"], pk["kmax"], pk["forcing"]["SST"], pk["sw"])
+    om = oracle.macros_source_sink(mtr, pk["kmax"])
+    rep = P.Report()
+    P.compare_tend(rep, "block.dms", dtend.transpose(2, 0, 1), np.where(active, m["h"][:, :, None] * od["tend"][0:2].transpose(1, 2, 0), 0.0).transpose(2, 0, 1))
+    P.compare_tend(rep, "block.macros", mtend.transpose(2, 0, 1), np.where(active, m["h"][:, :, None] * om["tend"][0:3].transpose(1, 2, 0), 0.0).transpose(2, 0, 1))
+    os_ = oracle.dms_surface_fluxes(dtr, frc)
+    rep.note("diag", "dms surface flux", P.e_norm(dsf, os_["netFlux"][0:2].T * CM_TO_M), P.TOL_DIAG)
+    assert rep.ok(), "\n".join(rep.fail[:10])
+    # accumulate on top of what the host holds, active cells only, all three arrays
+    a30, a2, a3 = np.full((nc, nz, 30), 5.0), np.full((nc, nz, 2), 5.0), np.full((nc, nz, 3), 5.0)
+    step(blk0, a30, a2, a3, True)                                 # blk0 has run one step: this is its second (warm pH: BGC only differs)
+    o30, o2, o3 = np.zeros((nc, nz, 30)), np.zeros((nc, nz, 2)), np.zeros((nc, nz, 3))
+    step(blk, o30, o2, o3, False)                                 # blk's second step, overwriting
+    assert np.array_equal(a30, np.where(active, 5.0 + o30, 5.0))
+    assert np.array_equal(a2, np.where(active, 5.0 + o2, 5.0)) and np.array_equal(a3, np.where(active, 5.0 + o3, 5.0))
+    assert E.lib.obgc_block_destroy(blk) == 0 and E.lib.obgc_block_destroy(blk0) == 0
