@@ -168,3 +168,23 @@ def test_fortran_binding_covers_the_resident_and_fused_entry_points():
     dev = open(os.path.join(ROOT, "ocean-bgc_amd", "fortran", "obgc_device.F90")).read()
     for name in ("hipMalloc", "hipFree", "hipMemcpy", "hipMemset"):
         assert "bind(C, name='%s')" % name in dev
+
+
+def test_build_guards_the_column_kernels_register_budget(tmp_path):
+    """csrc/check_resources.py fails the build when a bgc_column_kernel instantiation needs scratch, more than 256 registers
+    or more LDS than two workgroups per CU allow (the budget hangs on an internal compiler switch, csrc/Makefile)."""
+    import subprocess
+    import sys
+    chk = os.path.join(ROOT, "ocean-bgc_amd", "csrc", "check_resources.py")
+    rem = os.path.join(ROOT, "ocean-bgc_amd", "csrc", "build", "obgc_ecosys.remarks")
+    if not os.path.exists(rem):
+        pytest.skip("the library was not built here")
+    ok = subprocess.run([sys.executable, chk, rem], capture_output=True, text=True)
+    assert ok.returncode == 0 and "inside the budget" in ok.stdout, ok.stderr
+    text = open(rem, errors="replace").read()
+    for doctored in (re.sub(r"ScratchSize \[bytes/lane\]: 0", "ScratchSize [bytes/lane]: 152", text, count=1),
+                     re.sub(r"VGPRs: 2\d\d", "VGPRs: 300", text, count=1), "no kernels here"):
+        p = tmp_path / "bad.remarks"
+        p.write_text(doctored)
+        bad = subprocess.run([sys.executable, chk, str(p)], capture_output=True, text=True)
+        assert bad.returncode != 0 and "budget" in bad.stderr + bad.stdout
