@@ -182,8 +182,8 @@ def test_build_guards_the_column_kernels_register_budget(tmp_path):
     ok = subprocess.run([sys.executable, chk, rem], capture_output=True, text=True)
     assert ok.returncode == 0 and "inside the budget" in ok.stdout, ok.stderr
     text = open(rem, errors="replace").read()
-    for doctored in (re.sub(r"ScratchSize \[bytes/lane\]: 0", "ScratchSize [bytes/lane]: 152", text, count=1),
-                     re.sub(r"VGPRs: 2\d\d", "VGPRs: 300", text, count=1), "no kernels here"):
+    for doctored in (re.sub(r"ScratchSize \[bytes/lane\]: 0", "ScratchSize [bytes/lane]: 152", text),
+                     re.sub(r"VGPRs: 2\d\d", "VGPRs: 300", text), "no kernels here"):
         p = tmp_path / "bad.remarks"
         p.write_text(doctored)
         bad = subprocess.run([sys.executable, chk, str(p)], capture_output=True, text=True)
