@@ -363,6 +363,8 @@ struct CarbIn {
   double T, S, zmid, dic, alk, po4, sio3, php, pha;   // raw
 };
 
+// SHARED: the caller already holds T, S, zmid and the clamped PO4 and SiO3 of the cell and fills them in itself
+template <bool SHARED = false>
 __device__ __forceinline__ void carbonate_load(const BgcKernelArgs& A, int i_dic, int i_alk, int i_po4, int i_sio3, bool inside, int k,
                                                int c, CarbIn& in) {
   const GridView& g = A.g;
@@ -372,13 +374,15 @@ __device__ __forceinline__ void carbonate_load(const BgcKernelArgs& A, int i_dic
   const long long ix = in.ix;
   in.T = 10.0; in.S = 35.0; in.zmid = 0.0; in.dic = 2000.0; in.alk = 2300.0; in.po4 = 0.0; in.sio3 = 0.0; in.php = 0.0; in.pha = 0.0;
   if (in.live) {
-    in.T = A.temp[ix];
-    in.S = A.salt[ix];
-    in.zmid = A.zmid[ix];
+    if (!SHARED) {
+      in.T = A.temp[ix];
+      in.S = A.salt[ix];
+      in.zmid = A.zmid[ix];
+      in.po4 = A.tracers[(long long)(i_po4 - 1) * g.plane + ix];
+      in.sio3 = A.tracers[(long long)(i_sio3 - 1) * g.plane + ix];
+    }
     in.dic = A.tracers[(long long)(i_dic - 1) * g.plane + ix];
     in.alk = A.tracers[(long long)(i_alk - 1) * g.plane + ix];
-    in.po4 = A.tracers[(long long)(i_po4 - 1) * g.plane + ix];
-    in.sio3 = A.tracers[(long long)(i_sio3 - 1) * g.plane + ix];
     in.php = A.ph_prev[ix];
     in.pha = A.ph_prev_alt[ix];
   }

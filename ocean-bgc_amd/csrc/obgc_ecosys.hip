@@ -274,6 +274,8 @@ struct LevelIn {
   double L_no3, L_nh4, L_fe, L_sio3, L_po4, L_donr, L_dopr, L_dic, L_alk, L_o2;
   double oc0, d0, jc, jn, jp, jsi;   // DIAG only
   double chl100;                     // DIAG, column-block kernel only: chlorophyll x thickness above 100 m
+  double S, zmid, PO4c, SiO3c;       // column-block kernel that solves the carbonate system itself: what that block shares with
+                                     // the cell terms stays in registers instead of being read again (clamped PO4, SiO3)
 };
 
 // Dissolution length scales and decay factors across one level (2273-2339): cell-local functions of zbot, T, O2 and dz.
@@ -374,7 +376,7 @@ struct CellIn {
 // Every global load of a cell is issued here, back to back, before anything waits: ~45 independent requests per lane and a
 // single memory round trip per wavefront.  Cells below the sea floor load too (valid addresses, values discarded) so that
 // the kmax test does not cost a round trip of its own.  (k, c) must be inside the grid.
-template <bool DIAG, bool DM, bool COLK>
+template <bool DIAG, bool DM, bool COLK, bool CARB = false>
 __device__ __forceinline__ void cell_load(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, int k, int c,
                                           CellIn& in) {
   const GridView& g = A.g;
@@ -395,6 +397,7 @@ __device__ __forceinline__ void cell_load(const BgcKernelArgs& A, const obgc_bgc
   in.zb = 0.0; in.fesed = 0.0;
   if (COLK) { in.zb = A.zbot[ix]; in.fesed = A.fesed[ix]; }
   in.salt = 0.0; in.ztop = 0.0;
+  if (CARB && !DIAG) in.salt = A.salt[ix];
   if (DIAG) {
     in.salt = A.salt[ix];
     in.ztop = A.zbot[g.at(k > 0 ? k - 1 : 0, c)];
@@ -852,6 +855,7 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     ho[H_L_NO3][tid] = L_no3; ho[H_L_NH4][tid] = L_nh4; ho[H_L_FE][tid] = L_fe; ho[H_L_SIO3][tid] = L_sio3; ho[H_L_PO4][tid] = L_po4;
     ho[H_L_DONR][tid] = L_donr; ho[H_L_DOPR][tid] = L_dopr; ho[H_L_DIC][tid] = L_dic; ho[H_L_ALK][tid] = L_alk; ho[H_L_O2][tid] = L_o2;
     lo->dz = dz; lo->zb = zb; lo->NO3 = NO3; lo->O2 = dmax(0.0, r_O2); lo->Fe = Fe; lo->fesed = r_fesed; lo->T = T;
+    lo->S = r_salt; lo->zmid = zc; lo->PO4c = PO4; lo->SiO3c = SiO3;
     lo->prodPOC = prodPOC; lo->prodCa = prodCa; lo->prodSi = prodSi; lo->PfeLoc = PfeLoc;
     // what the walking wavefront would otherwise read from HBM again or compute at one lane per column
     const LevelDerived dv = derive_level(P, zb, Tfunc, dmax(0.0, r_O2), dz);
@@ -1410,7 +1414,7 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     // order, so these loads wait for every store before them -- was measured and lost: the ~50 values live across a chunk
     // boundary cost more in spills than the wait, 44.9 ms against 41.3 ms at 1 M columns x 80 levels.)
     CellIn in;
-    cell_load<DIAG, DM, true>(*Ap, *Pp, DM ? Fp : nullptr, kc, cc, in);
+    cell_load<DIAG, DM, true, FUSE != 0>(*Ap, *Pp, DM ? Fp : nullptr, kc, cc, in);
     if (DIAG && j > 0) {   // the chunk above has left its integrands in the slots; this chunk's loads are in flight
       lds_barrier();
       integrate_chunk<FUSE>(s_ho, s_int, role, lane, kmax, j - 1);
@@ -1465,7 +1469,10 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     // The carbonate block's nine inputs are requested HERE, ahead of the stores of the finish phase: vector memory
     // operations complete in issue order, so requested behind them they would wait for every one of them.
     CarbIn cin;
-    if (FUSE) carbonate_load(*Ap, Pp->ind[6], Pp->ind[8], Pp->ind[0], Pp->ind[2], X.valid, X.k, X.valid ? c : 0, cin);
+    if (FUSE) {
+      carbonate_load<true>(*Ap, Pp->ind[6], Pp->ind[8], Pp->ind[0], Pp->ind[2], X.valid, X.k, X.valid ? c : 0, cin);
+      if (cin.live) { cin.T = lo.T; cin.S = lo.S; cin.zmid = lo.zmid; cin.po4 = lo.PO4c; cin.sio3 = lo.SiO3c; }
+    }
     double zmid_i = 0.0;   // depth of the cell centre, for the O2 minimum and the saturation horizons
     if (DIAG && !FUSE && active) zmid_i = Ap->zmid[g.at(X.k, c)];
     JTerms jt{0.0, 0.0, 0.0, 0.0};
