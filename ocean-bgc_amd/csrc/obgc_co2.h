@@ -460,8 +460,11 @@ __device__ __forceinline__ void carbonate_solve(const BgcKernelArgs& A, bool ins
     if (differs) h2 = h2s;
   }
 
-  double sat_calc, sat_arag;
-  comp_co3_sat_vals(deep, depth, T, S, sat_calc, sat_arag);
+  // the saturation concentrations feed diagnostics and the saturation-horizon search only (BGC_mod.F90:995-1032): a call
+  // that writes neither skips their ~300 instructions per cell (wave-uniform test)
+  double sat_calc = 0.0, sat_arag = 0.0;
+  if (out || A.sat_calc_out || A.sat_arag_out || (A.have_diag && (A.diag.co3_sat_calc || A.diag.co3_sat_arag)))
+    comp_co3_sat_vals(deep, depth, T, S, sat_calc, sat_arag);
 
   if (!inside) return;
   if (live) {
