@@ -197,7 +197,14 @@ class Workload:
         self.fused = bool(fused) and ("dms" in modules and "macros" in modules) and hasattr(eng, "fused_step")
         # the separate DMS / MACROS entry points keep scratch in the caller's index space: native layout only
         self.tiled = layout == "tiled" and (self.fused or not ("dms" in modules or "macros" in modules))
-        self.nbuf = 1 if ph == "warm" else max(1, min(steps, 8))
+        # cold start per step: every timed step finds a zeroed pH pair of its own resident before the timed region when
+        # device memory allows (two planes per step); otherwise 8 pairs rotate and are cleared again inside the timing
+        self.nbuf = 1
+        if ph != "warm":
+            plane = ((ncol + 63) // 64) * 64 * nz * 8
+            n_base = 30 + 6 + 30 + 24 + (200 if diag_on else 0)
+            free = torch.cuda.mem_get_info()[0]
+            self.nbuf = max(1, steps if (n_base + 2 * steps) * plane < 0.8 * free and steps <= 64 else min(steps, 8))
         with_own = "dms" in modules or "macros" in modules or "dms_surf" in modules
         with_dtr = ("dms" in modules or "dms_surf" in modules) and (not self.fused or "dms_surf" in modules)
         if self.tiled:
@@ -230,8 +237,10 @@ class Workload:
         own = KC(5) if with_own else None
         dtr = KC(14) if with_dtr else None
         self.tend = KC(30)
-        # cold start per step: a zeroed pH state pair per step, rotated over at most 8 buffers
-        self.phs = [(KC().zero_(), KC().zero_()) for _ in range(self.nbuf)]
+        # adjacent planes, so that one fill clears them all
+        self.ph_all = KC(2 * self.nbuf)
+        self.phs = [(plane_of(self.ph_all, 2 * i), plane_of(self.ph_all, 2 * i + 1)) for i in range(self.nbuf)]
+        self.rezero()
         self.diag = None
         if diag_on:
             d = {}
@@ -356,8 +365,7 @@ class Workload:
                     self.kms["macros"].append(eng.last_kernel_ms(0))
 
     def rezero(self):
-        for p in self.phs:
-            p[0].zero_(); p[1].zero_()
+        self.ph_all.zero_()
         self.torch.cuda.synchronize()
 
     def timed(self, steps, warmup, barrier):
@@ -374,7 +382,7 @@ class Workload:
         for i in range(steps):
             self.step(i, True)                # engine calls are synchronous: each returns with its kernels done
             if self.ph == "cold" and (i + 1) % self.nbuf == 0 and i + 1 < steps:
-                self.rezero()                 # keeps every timed step cold; 2 small memsets per 8 steps, inside the timing
+                self.rezero()                 # (only when memory did not allow a pair per step) inside the timing
         barrier()
         return time.perf_counter() - t0
 
