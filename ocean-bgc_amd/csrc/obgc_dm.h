@@ -38,13 +38,13 @@ __device__ __forceinline__ DmsColumn dms_column_terms(const obgc_dms_params& P, 
 
 // One active cell of DMS_SourceSink.  Every tracer value is already clamped at zero (DMS_mod.F90:471-485); PAR_avg is the
 // level mean of PAR (551).  Writes the 27 diagnostics at index ix when DIAG; returns the two tendencies (718-719).
-template <bool DIAG>
+template <bool DIAG, bool FD = false>   // FD: every diagnostic was passed, no per-member test
 __device__ __forceinline__ void dms_cell_terms(const obgc_dms_params& P, const obgc_dms_diag& D, long long ix, const DmsColumn& col,
                                                double DMS, double DMSP, double zooC, double spC, double spCaCO3, double diatC,
                                                double diazC, double phaeoC, double spChl, double PAR_avg, double& t_dms,
                                                double& t_dmsp, bool live = true) {
 // live = false: a lane below the sea floor that runs along (column-block kernel); the reference leaves these diagnostics alone there
-#define ST(name, v) do { if (DIAG && live && D.name) OBGC_STORE(&D.name[ix], (v)); } while (0)
+#define ST(name, v) do { if (DIAG && live && (FD || D.name)) OBGC_STORE(&D.name[ix], (v)); } while (0)
   const double k_S_p = P.k_S_p_base * (P.mort + (zooC / 0.3));          // 529: hard-wired 0.3, not zooC_avg
   const double j_dms = P.j_dms_perI * PAR_avg;
   // community partition (570-612)
@@ -99,7 +99,7 @@ __device__ __forceinline__ void dms_cell_terms(const obgc_dms_params& P, const o
 }
 
 // One active cell of MACROS_SourceSink (MACROS_mod.F90:349-402); tracer values already clamped at zero (301-325).
-template <bool DIAG>
+template <bool DIAG, bool FD = false>
 __device__ __forceinline__ void macros_cell_terms(const obgc_macros_params& P, const obgc_macros_diag& D, long long ix, double zooC,
                                                   double spC, double diatC, double diazC, double phaeoC, double PROT, double POLY,
                                                   double LIP, double& t_prot, double& t_poly, double& t_lip, bool live = true) {
@@ -113,12 +113,12 @@ __device__ __forceinline__ void macros_cell_terms(const obgc_macros_params& P, c
   t_poly = poly_s - poly_r;
   t_lip = lip_s - lip_r;
   if (DIAG && live) {
-    if (D.PROT_S_TOTAL) D.PROT_S_TOTAL[ix] = prot_s;
-    if (D.POLY_S_TOTAL) D.POLY_S_TOTAL[ix] = poly_s;
-    if (D.LIP_S_TOTAL) D.LIP_S_TOTAL[ix] = lip_s;
-    if (D.PROT_R_TOTAL) D.PROT_R_TOTAL[ix] = prot_r;
-    if (D.POLY_R_TOTAL) D.POLY_R_TOTAL[ix] = poly_r;
-    if (D.LIP_R_TOTAL) D.LIP_R_TOTAL[ix] = lip_r;
+    if (FD || D.PROT_S_TOTAL) D.PROT_S_TOTAL[ix] = prot_s;
+    if (FD || D.POLY_S_TOTAL) D.POLY_S_TOTAL[ix] = poly_s;
+    if (FD || D.LIP_S_TOTAL) D.LIP_S_TOTAL[ix] = lip_s;
+    if (FD || D.PROT_R_TOTAL) D.PROT_R_TOTAL[ix] = prot_r;
+    if (FD || D.POLY_R_TOTAL) D.POLY_R_TOTAL[ix] = poly_r;
+    if (FD || D.LIP_R_TOTAL) D.LIP_R_TOTAL[ix] = lip_r;
   }
 }
 

@@ -419,7 +419,9 @@ __device__ __forceinline__ void cell_load(const BgcKernelArgs& A, const obgc_bgc
 // COLK only: *lo receives what the cell's finishing arithmetic needs once the recurrence has passed (the local parts of
 // the ten particle-dependent tendencies, the local parts of its diagnostics); the return value says whether this lane
 // evaluated an active cell.  `in` = the cell's loaded values (cell_load) for the cell (k, c) given here.
-template <bool DIAG, bool DM, bool COLK>
+// FD: the caller has checked that every diagnostic the routine writes was passed: no per-member test (two scalar
+// instructions a store, ~300 per cell).
+template <bool DIAG, bool DM, bool COLK, bool FD = false>
 __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc_params& P, const FusedDmArgs* F, const FusedParams* FP,
                                           const ColCtx* X, LevelIn<DIAG>* lo, int k, int c, const CellIn& in) {
   const GridView& g = A.g;
@@ -435,8 +437,8 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
 // SAME store instructions: Z(v) = 0 for it.  A wavefront that straddles the floor -- one in five at 1 M x 80 -- then issues
 // every store once, over full rows, instead of once per side of the floor.
 #define Z(v) (live ? (v) : 0.0)
-#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
-#define ST_KCA(name, a, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[(long long)(a) * pl + ix], Z(v)); } while (0)
+#define ST_KC(name, v) do { if (DIAG && (FD || D.name)) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
+#define ST_KCA(name, a, v) do { if (DIAG && (FD || D.name)) OBGC_STORE(&D.name[(long long)(a) * pl + ix], Z(v)); } while (0)
 #define ST_TEND(slot, v) OBGC_STORE(&TEND(slot), Z(v))
   bool live = true;
   int kmax = in.kmax;
@@ -515,14 +517,14 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       const double PAR_avg_dms = dflag ? d_parin * (1.0 - d_att) / d_kpardz : PAR_avg;
       const DmsColumn col = dms_column_terms(FP->dms, o_sst);
       double t_dms, t_dmsp;
-      dms_cell_terms<true>(FP->dms, F->ddiag, ix, col, dmax(0.0, o_dms), dmax(0.0, o_dmsp), c_zoo, c_sp, dmax(0.0, o_spca), c_diat,
+      dms_cell_terms<true, FD>(FP->dms, F->ddiag, ix, col, dmax(0.0, o_dms), dmax(0.0, o_dmsp), c_zoo, c_sp, dmax(0.0, o_spca), c_diat,
                            c_diaz, c_phaeo, dmax(0.0, pick_Chl(raw, P.sp_ind - 1)), PAR_avg_dms, t_dms, t_dmsp, live);
       F->dms_tend[ix] = Z(t_dms);
       F->dmsp_tend[ix] = Z(t_dmsp);
     }
     if (F->prot) {
       double t_prot, t_poly, t_lip;
-      macros_cell_terms<true>(FP->macros, F->mdiag, ix, c_zoo, c_sp, c_diat, c_diaz, c_phaeo, dmax(0.0, o_prot), dmax(0.0, o_poly),
+      macros_cell_terms<true, FD>(FP->macros, F->mdiag, ix, c_zoo, c_sp, c_diat, c_diaz, c_phaeo, dmax(0.0, o_prot), dmax(0.0, o_poly),
                               dmax(0.0, o_lip), t_prot, t_poly, t_lip, live);
       F->prot_tend[ix] = Z(t_prot);
       F->poly_tend[ix] = Z(t_poly);
@@ -1100,14 +1102,14 @@ struct JTerms { double C, N, P, Si; };
 
 // The rest of the level, cell-local once the recurrence has passed: denitrification, the particle-dependent part of 11
 // tendencies and 27 diagnostics (1569-1577, 1583-1790, 2637-2694).  Stores go to the caller's arrays at index ix.
-template <bool DIAG>
+template <bool DIAG, bool FD = false>
 __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, const LevelIn<DIAG>& cur,
                                                const SweepCoreOut& o, bool live = true) {
   const obgc_bgc_diag& D = A.diag;
   const long long pl = A.g.plane;
 #define TEND(slot, ix) A.tend[(long long)((slot)-1) * pl + (ix)]
 #define Z(v) (live ? (v) : 0.0)      // a cell below the sea floor (column-block kernel only): the reference's zero fill
-#define ST_KC(name, v) do { if (DIAG && D.name) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
+#define ST_KC(name, v) do { if (DIAG && (FD || D.name)) OBGC_STORE(&D.name[ix], Z(v)); } while (0)
   const double dz = cur.dz, NO3 = dmax(0.0, cur.NO3), O2 = dmax(0.0, cur.O2);
   const double prodPOC = cur.prodPOC, prodCa = cur.prodCa, prodSi = cur.prodSi;
   const double reminPOC = o.reminPOC, reminCa = o.reminCa, reminSi = o.reminSi, reminFe = o.reminFe, Fe_scavenge = o.Fe_scavenge,
@@ -1358,7 +1360,7 @@ __device__ unsigned long long g_coltiming[8][kColLevels];
 #define OBGC_T(i) do { } while (0)
 #endif
 
-template <bool DIAG, bool DM, int FUSE>
+template <bool DIAG, bool DM, int FUSE, bool FD = false>
 __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKernelArgs A, const obgc_bgc_params P, const FusedDmArgs F,
                                                                     const FusedParams FP) {
   __shared__ double s_ho[H_NSLOTS][kColThreads];
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     OBGC_T(0);   // the chunk's loads (behind the stores of the chunk before)
 #endif
-    const bool active = cell_body<DIAG, DM, true>(*Ap, *Pp, DM ? Fp : nullptr, DM ? FPp : nullptr, &X, &lo, kc, cc, in);
+    const bool active = cell_body<DIAG, DM, true, FD>(*Ap, *Pp, DM ? Fp : nullptr, DM ? FPp : nullptr, &X, &lo, kc, cc, in);
     OBGC_T(1);   // cell terms (with the light barrier inside)
     lds_barrier();   // the chunk's recurrence inputs are in LDS
     OBGC_T(2);
@@ -1492,7 +1494,7 @@ __global__ __launch_bounds__(kColThreads, 2) void bgc_column_kernel(const BgcKer
       lo.L_no3 = s_ho[H_L_NO3][t]; lo.L_nh4 = s_ho[H_L_NH4][t]; lo.L_fe = s_ho[H_L_FE][t]; lo.L_sio3 = s_ho[H_L_SIO3][t];
       lo.L_po4 = s_ho[H_L_PO4][t]; lo.L_donr = s_ho[H_L_DONR][t]; lo.L_dopr = s_ho[H_L_DOPR][t]; lo.L_dic = s_ho[H_L_DIC][t];
       lo.L_alk = s_ho[H_L_ALK][t]; lo.L_o2 = s_ho[H_L_O2][t];
-      jt = sweep_finish<DIAG>(*Ap, *Pp, ix, lo, o, X.k < kmax);
+      jt = sweep_finish<DIAG, FD>(*Ap, *Pp, ix, lo, o, X.k < kmax);
     }
     OBGC_T(5);   // finish
     // no barrier here: the next chunk's first write into the slots sits behind its light barrier
@@ -1656,8 +1658,35 @@ void launch_bgc_column(const BgcKernelArgs& a, const obgc_bgc_params& p, const F
   const FusedDmArgs& F = f ? *f : f0;
   const FusedParams& FP = fp ? *fp : fp0;
 #define OBGC_LAUNCH_COL(DIAG, DM, FUSE) hipLaunchKernelGGL((bgc_column_kernel<DIAG, DM, FUSE>), dim3(grid), dim3(kColThreads), 0, s, a, p, F, FP)
+#define OBGC_LAUNCH_COL_FD(DM, FUSE) hipLaunchKernelGGL((bgc_column_kernel<true, DM, FUSE, true>), dim3(grid), dim3(kColThreads), 0, s, a, p, F, FP)
   const bool dm = f != nullptr;
-  if (a.have_diag) {
+  // every diagnostic the cell terms and the finishing arithmetic store (and, in the fused step, every one of DMS and MACROS)
+  bool full = a.have_diag != 0;
+  if (full) {
+    // (three members of the reference's type are never written: BGC_mod.F90 has no statement for them)
+#define X(n) full = full && (a.diag.n != nullptr || !std::strcmp(#n, "POC_ACCUM") || !std::strcmp(#n, "DONr_remin") || !std::strcmp(#n, "DOPr_remin"));
+    OBGC_BGC_DIAG_KC(X)
+#undef X
+#define X(n) full = full && a.diag.n != nullptr;
+    OBGC_BGC_DIAG_KCA(X)
+#undef X
+    if (dm && f->dms) {
+      full = full && f->have_ddiag;
+#define X(n) full = full && f->ddiag.n != nullptr;
+      OBGC_DMS_DIAG_KC(X)
+#undef X
+    }
+    if (dm && f->prot) {
+      full = full && f->have_mdiag;
+#define X(n) full = full && f->mdiag.n != nullptr;
+      OBGC_MACROS_DIAG_KC(X)
+#undef X
+    }
+  }
+  if (full) {
+    if (dm) { if (fuse_carbonate) OBGC_LAUNCH_COL_FD(true, 1); else OBGC_LAUNCH_COL_FD(true, 0); }
+    else { if (fuse_carbonate) OBGC_LAUNCH_COL_FD(false, 1); else OBGC_LAUNCH_COL_FD(false, 0); }
+  } else if (a.have_diag) {
     if (dm) { if (fuse_carbonate) OBGC_LAUNCH_COL(true, true, 1); else OBGC_LAUNCH_COL(true, true, 0); }
     else { if (fuse_carbonate) OBGC_LAUNCH_COL(true, false, 1); else OBGC_LAUNCH_COL(true, false, 0); }
   } else {
@@ -1665,6 +1694,7 @@ void launch_bgc_column(const BgcKernelArgs& a, const obgc_bgc_params& p, const F
     else { if (fuse_carbonate) OBGC_LAUNCH_COL(false, false, 1); else OBGC_LAUNCH_COL(false, false, 0); }
   }
 #undef OBGC_LAUNCH_COL
+#undef OBGC_LAUNCH_COL_FD
 #ifdef OBGC_COLTIMING
   {
     (void)hipDeviceSynchronize();
