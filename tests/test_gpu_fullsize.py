@@ -91,24 +91,29 @@ def test_cfg2_100k_x_60_properties(gpu, oracle, synth):
     for nm in ("Jint_Ctot", "zsatarag", "photoC_NO3_TOT_zint"):
         assert torch.equal(s["diag"][nm], b["diag"][nm][w0:w0 + wn]), nm
     assert torch.equal(s["diag"]["light_lim"], b["diag"]["light_lim"][:, :, w0:w0 + wn])
+    # strided sample of the cold call, every output (the warm call below overwrites the diagnostics)
+    cols = np.arange(0, nc, 397)
+    got = dict(tend=tend1[:, :, cols].cpu().numpy().transpose(0, 2, 1), ph_prev=ph1[0][:, cols].cpu().numpy().T,
+               ph_prev_alt=ph1[1][:, cols].cpu().numpy().T,
+               kc={nm: b["diag"][nm][:, cols].cpu().numpy().T for nm in L.BGC_DIAG_KC},
+               kca={nm: b["diag"][nm][:, :, cols].cpu().numpy().transpose(0, 2, 1) for nm in L.BGC_DIAG_KCA},
+               ca={nm: b["diag"][nm][:, cols].cpu().numpy() for nm in L.BGC_DIAG_CA},
+               c={nm: b["diag"][nm][cols].cpu().numpy() for nm in L.BGC_DIAG_C})
     # warm start from the converged state reproduces the pH to the reference solver's accuracy:
     # xacc = 1e-10 on [H+] ~ 1e-8 (co2calc.F90:47-53, "3 significant figures") -> |dpH| <~ 4e-3
     cold = ph1.clone()
     run(L, eng, b)       # b["ph"] now holds the cold solution -> narrow bracket
     live = ~below
     assert float((b["ph"][0][live] - cold[0][live]).abs().max()) < 5e-3
-    # strided sample against the oracle (inputs are bit-identical to the numpy generator)
-    cols = np.arange(0, nc, 397)
+    # the sample against the oracle, diagnostics and column integrals included (inputs are bit-identical to the numpy generator)
     tr_h = b["tr"][:, :, cols].cpu().numpy().transpose(0, 2, 1)
     kc_h = {nm: v[:, cols].cpu().numpy().T for nm, v in b["kc"].items()}
     cc_h = {nm: v[cols].cpu().numpy() for nm, v in b["cc"].items()}
     z = np.zeros((cols.size, nz))
     want = oracle.bgc_source_sink(tr_h, kc_h["temp"], kc_h["salt"], kc_h["zmid"], kc_h["dz"], kc_h["zbot"], cc_h["lat"],
                                   b["kmax"][cols].cpu().numpy(), kc_h["fesedflux"], cc_h["dust_flux_in"], cc_h["sw_flux"], z, z,
-                                  diagnostics=False)
-    rep = P.Report()
-    P.compare_tend(rep, "tend", tend1[:, :, cols].cpu().numpy().transpose(0, 2, 1), want["tend"])
-    rep.note("ph", "ph_prev", P.e_norm(ph1[0][:, cols].cpu().numpy().T, want["ph_prev"]), P.TOL_PH)
+                                  diag_init=-7.0)
+    rep = P.compare_bgc(got, want)
     assert rep.ok(), "\n".join(rep.fail[:8])
 
 
@@ -282,7 +287,8 @@ def test_cfg4_1M_x_80_fused_step_properties(gpu, oracle, synth):
         for nm, v in so[grp].items():
             assert torch.equal(v, o[grp][nm][:, w0:w0 + wn]), nm
     del s, so
-    # strided sample against the oracle: BGC tendencies and pH, DMS and MACROS tendencies and diagnostics
+    # strided sample against the oracle: every BGC output (diagnostics and column integrals included), DMS and MACROS
+    # tendencies and diagnostics
     cols = np.arange(0, nc, 3989)
     sel = torch.as_tensor(cols, device="cuda")
     h = lambda x: x.index_select(-1, sel).cpu().numpy()
@@ -292,10 +298,12 @@ def test_cfg4_1M_x_80_fused_step_properties(gpu, oracle, synth):
     kmax_h = h(b["kmax"])
     z = np.zeros((cols.size, nz))
     want = oracle.bgc_source_sink(tr_h, kc_h["temp"], kc_h["salt"], kc_h["zmid"], kc_h["dz"], kc_h["zbot"], cc_h["lat"], kmax_h,
-                                  kc_h["fesedflux"], cc_h["dust_flux_in"], cc_h["sw_flux"], z, z, diagnostics=False)
-    rep = P.Report()
-    P.compare_tend(rep, "tend", h(tend1).transpose(0, 2, 1), want["tend"])
-    rep.note("ph", "ph_prev", P.e_norm(h(ph1[0]).T, want["ph_prev"]), P.TOL_PH)
+                                  kc_h["fesedflux"], cc_h["dust_flux_in"], cc_h["sw_flux"], z, z, diag_init=-7.0)
+    got = dict(tend=h(tend1).transpose(0, 2, 1), ph_prev=h(ph1[0]).T, ph_prev_alt=h(ph1[1]).T,
+               kc={nm: h(b["diag"][nm]).T for nm in L.BGC_DIAG_KC},
+               kca={nm: h(b["diag"][nm]).transpose(0, 2, 1) for nm in L.BGC_DIAG_KCA},
+               ca={nm: h(b["diag"][nm]) for nm in L.BGC_DIAG_CA}, c={nm: h(b["diag"][nm]) for nm in L.BGC_DIAG_C})
+    rep = P.compare_bgc(got, want)
     own_h = h(o["own"]).transpose(0, 2, 1)                       # [5, c, k]
     named = {nm: tr_h[i] for i, nm in enumerate(L.BGC_TRACERS)}
     named.update(dms=own_h[0], dmsp=own_h[1], prot=own_h[2], poly=own_h[3], lip=own_h[4])
