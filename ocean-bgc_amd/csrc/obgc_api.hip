@@ -372,6 +372,7 @@ extern "C" int obgc_set_bgc_params(obgc_handle* h, const obgc_bgc_params* p) {
   if (p->lrest_po4 || p->lrest_no3 || p->lrest_sio3)
     return fail(h, OBGC_ERR_UNSUPPORTED, "nutrient restoring (lrest_*) is dead code in the reference and not provided");
   h->bgc = *p;
+  h->bgc_recip_valid = false;
   return OBGC_OK;
 }
 extern "C" int obgc_set_dms_params(obgc_handle* h, const obgc_dms_params* p) {
@@ -518,6 +519,16 @@ int bgc_launch_column(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, co
   HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux2_done, 0));
+  return OBGC_OK;
+}
+
+// the reciprocals of the shared divisors for the handle's parameters (BgcKernelArgs::recip), computed when they changed
+inline int bgc_recips(obgc_handle* h, BgcKernelArgs& K) {
+  if (!h->bgc_recip_valid) {
+    HIP_TRY(h, bgc_recips_compute(h->bgc, h->bgc_recip, h->s_main));
+    h->bgc_recip_valid = true;
+  }
+  std::memcpy(K.recip, h->bgc_recip, sizeof K.recip);
   return OBGC_OK;
 }
 
@@ -908,6 +919,8 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   K.diag = dd;
   K.have_diag = a->diag ? 1 : 0;
   K.alt_co2_use_eco = a->alt_co2_use_eco;
+  rc = bgc_recips(h, K);
+  if (rc != OBGC_OK) return rc;
 
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
   if (!tiled) {
@@ -1059,6 +1072,8 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   if (b.diag) K.diag = *b.diag;
   K.have_diag = b.diag ? 1 : 0;
   K.alt_co2_use_eco = b.alt_co2_use_eco;
+  rc = bgc_recips(h, K);
+  if (rc != OBGC_OK) return rc;
   bgc_carve_scratch(h, K, want_zsat, column);
 
   FusedDmArgs F;

@@ -33,6 +33,7 @@
 // last); the change is a few ulp of the largest term, far inside the parity bar.
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "obgc_co2.h"
 #include "obgc_dm.h"
@@ -285,19 +286,19 @@ struct LevelDerived {
   double decay_POC_E, decay_SiO2, decay_CaCO3, decay_dust, DECAY_Hard, DECAY_HardDust;
 };
 
-__device__ __forceinline__ LevelDerived derive_level(const obgc_bgc_params& P, double zb, double TfuncS, double O2, double dz) {
+__device__ __forceinline__ LevelDerived derive_level(const obgc_bgc_params& P, const double* rc, double zb, double TfuncS, double O2, double dz) {
   double scalelength;
   {
     const double* sz = P.parm_scalelen_z;
     const double* sv = P.parm_scalelen_vals;
     if (zb < sz[0]) scalelength = sv[0];
     else if (zb >= sz[3]) scalelength = sv[3];
-    else if (zb < sz[1]) scalelength = sv[0] + (sv[1] - sv[0]) * (zb - sz[0]) / (sz[1] - sz[0]);
-    else if (zb < sz[2]) scalelength = sv[1] + (sv[2] - sv[1]) * (zb - sz[1]) / (sz[2] - sz[1]);
-    else scalelength = sv[2] + (sv[3] - sv[2]) * (zb - sz[2]) / (sz[3] - sz[2]);
+    else if (zb < sz[1]) scalelength = sv[0] + div_by((sv[1] - sv[0]) * (zb - sz[0]), sz[1] - sz[0], rc[R_SCALELEN_DZ]);
+    else if (zb < sz[2]) scalelength = sv[1] + div_by((sv[2] - sv[1]) * (zb - sz[1]), sz[2] - sz[1], rc[R_SCALELEN_DZ + 1]);
+    else scalelength = sv[2] + div_by((sv[3] - sv[2]) * (zb - sz[2]), sz[3] - sz[2], rc[R_SCALELEN_DZ + 2]);
   }
   double poc_diss = P.parm_POC_diss;
-  if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + (3.3 - 1.0) * (40.0 - O2) / 35.0);
+  if ((O2 >= 5.0) && (O2 < 40.0)) poc_diss = P.parm_POC_diss * (1.0 + div_by((3.3 - 1.0) * (40.0 - O2), 35.0, rc[R_35]));
   else if (O2 < 5.0) poc_diss = P.parm_POC_diss * 3.3;
   poc_diss = scalelength * poc_diss;
   double sio2_diss = scalelength * P.parm_SiO2_diss;
@@ -307,7 +308,7 @@ __device__ __forceinline__ LevelDerived derive_level(const obgc_bgc_params& P, d
   LevelDerived d;
   d.poc_diss = poc_diss; d.sio2_diss = sio2_diss; d.caco3_diss = caco3_diss;
   d.decay_POC_E = exp(-dz / poc_diss); d.decay_SiO2 = exp(-dz / sio2_diss); d.decay_CaCO3 = exp(-dz / caco3_diss);
-  d.decay_dust = exp(-dz / dust_diss); d.DECAY_Hard = exp(-dz / 4.0e6); d.DECAY_HardDust = exp(-dz / 1.2e7);
+  d.decay_dust = exp(-dz / dust_diss); d.DECAY_Hard = exp(div_by(-dz, 4.0e6, rc[R_4E6])); d.DECAY_HardDust = exp(div_by(-dz, 1.2e7, rc[R_12E7]));
   return d;
 }
 
@@ -564,13 +565,14 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       NITRIF = P.parm_kappa_nitrif * NH4;
       if (PAR_in > P.parm_nitrif_par_lim) NITRIF = NITRIF * log(PAR_out / P.parm_nitrif_par_lim) / (-KPARdz);
     } else NITRIF = 0.0;
-    double wd = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
+    double wd = div_by((P.parm_o2_min + P.parm_o2_min_delta) - O2, P.parm_o2_min_delta, A.recip[R_O2DELTA]);
     wd = dmin(dmax(wd, 0.0), 1.0);
     if (NO3 == 0.0) wd = 0.0;
-    double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
+    double wo = div_by(O2 - P.parm_o2_min, P.parm_o2_min_delta, A.recip[R_O2DELTA]);
     wo = dmin(dmax(wo, 0.0), 1.0);
     s_tail[0][tid] = DOC_remin; s_tail[1][tid] = DON_remin; s_tail[2][tid] = DOFe_remin; s_tail[3][tid] = DOP_remin;
-    s_tail[4][tid] = DONr_remin; s_tail[5][tid] = DOPr_remin; s_tail[6][tid] = NITRIF; s_tail[7][tid] = wd * (DOC_remin / DENITRIF_C_N);
+    s_tail[4][tid] = DONr_remin; s_tail[5][tid] = DOPr_remin; s_tail[6][tid] = NITRIF;
+    s_tail[7][tid] = wd * div_by(DOC_remin, DENITRIF_C_N, A.recip[R_DENITRIF]);
     s_tail[8][tid] = wo;
     if (DIAG && D.AOU) aou = o2sat(T, r_salt, T0K) - O2;
   }
@@ -581,7 +583,7 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
   }
 
   // temperature response and loss thresholds (1041-1055)
-  const double Tfunc = exp((((T + T0K) - (TREF + T0K)) / 10.0) * LN_Q_10);   // Q_10 ** ((T + T0) - (Tref + T0)) / 10)
+  const double Tfunc = exp(div_by((T + T0K) - (TREF + T0K), 10.0, A.recip[R_TEN]) * LN_Q_10);   // Q_10 ** ((T + T0) - (Tref + T0)) / 10)
   double f_loss_thres;
   if (zc > THRES_Z1) f_loss_thres = (zc < THRES_Z2) ? (THRES_Z2 - zc) / (THRES_Z2 - THRES_Z1) : 0.0;
   else f_loss_thres = 1.0;
@@ -650,13 +652,13 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     const double Qfe = p.Fe / Cden;
     const double Qsi = (t.Si_ind > 0) ? dmin(p.Si / Cden, GQSI_MAX) : 0.0;
     double gQfe = t.gQfe_0;
-    if (Fe < CKS * t.kFe) gQfe = dmax((gQfe * Fe / (CKS * t.kFe)), t.gQfe_min);
+    if (Fe < CKS * t.kFe) gQfe = dmax(div_by(gQfe * Fe, CKS * t.kFe, A.recip[R_CKS_KFE + a]), t.gQfe_min);
     double gQsi = 0.0;
     if (t.Si_ind > 0) {
       gQsi = GQSI_0;
       if ((Fe < CKSI * t.kFe) && (Fe > 0.0) && (SiO3 > (CKSI * t.kSiO3))) gQsi = dmin((gQsi * CKSI * t.kFe / Fe), GQSI_MAX);
       if (Fe == 0.0) gQsi = GQSI_MAX;
-      if (SiO3 < (CKSI * t.kSiO3)) gQsi = dmax((gQsi * SiO3 / (CKSI * t.kSiO3)), GQSI_MIN);
+      if (SiO3 < (CKSI * t.kSiO3)) gQsi = dmax(div_by(gQsi * SiO3, CKSI * t.kSiO3, A.recip[R_CKSI_KSIO3 + a]), GQSI_MIN);
     }
     double QCa = 0.0;
     if (t.CaCO3_ind > 0) {
@@ -664,7 +666,7 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
       if (QCa > QCACO3_MAX) QCa = QCACO3_MAX;
     }
     // nutrient limitation (1108-1139)
-    const double rNO3 = NO3 / t.kNO3, rNH4 = NH4 / t.kNH4;
+    const double rNO3 = div_by(NO3, t.kNO3, A.recip[R_KNO3 + a]), rNH4 = div_by(NH4, t.kNH4, A.recip[R_KNH4 + a]);
     const double VNO3 = rNO3 / (1.0 + rNO3 + rNH4);
     const double VNH4 = rNH4 / (1.0 + rNO3 + rNH4);
     double VNtot = VNO3 + VNH4;
@@ -673,7 +675,7 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     const double VFe = Fe / (Fe + t.kFe);
     ST_KCA(Fe_lim, a, VFe);
     double f_nut = dmin(VNtot, VFe);
-    const double rPO4 = PO4 / t.kPO4, rDOP = DOP / t.kDOP;
+    const double rPO4 = div_by(PO4, t.kPO4, A.recip[R_KPO4 + a]), rDOP = div_by(DOP, t.kDOP, A.recip[R_KDOP + a]);
     const double VPO4 = rPO4 / (1.0 + rPO4 + rDOP);
     const double VDOP = rDOP / (1.0 + rPO4 + rDOP);
     const double VPtot = VPO4 + VDOP;
@@ -788,10 +790,13 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     if (photoC > 0.0) {   // O2 production (1767-1782)
       if (!t.Nfixer) {
         const double den = NO3_V + NH4_V;
-        O2_PRODUCTION = O2_PRODUCTION + photoC * ((NO3_V / den) / RED_D_C_O2 + (NH4_V / den) / REMIN_D_C_O2);
+        O2_PRODUCTION = O2_PRODUCTION + photoC * (div_by(NO3_V / den, RED_D_C_O2, A.recip[R_RED]) +
+                                                  div_by(NH4_V / den, REMIN_D_C_O2, A.recip[R_REMIN]));
       } else {
         const double den = NO3_V + NH4_V + Nfix;
-        O2_PRODUCTION = O2_PRODUCTION + photoC * ((NO3_V / den) / RED_D_C_O2 + (NH4_V / den) / REMIN_D_C_O2 + (Nfix / den) / RED_D_C_O2_DIAZ);
+        O2_PRODUCTION = O2_PRODUCTION + photoC * (div_by(NO3_V / den, RED_D_C_O2, A.recip[R_RED]) +
+                                                  div_by(NH4_V / den, REMIN_D_C_O2, A.recip[R_REMIN]) +
+                                                  div_by(Nfix / den, RED_D_C_O2_DIAZ, A.recip[R_RED_DIAZ]));
       }
     }
     // autotroph tendencies (1676-1697)
@@ -829,7 +834,7 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
   //      involve the particle remineralisation, weighted in the prologue; the sweep adds  w * (remin terms)  ----
   const double S3 = zoo_loss_dic + s_ls_dic + s_gr_dic;
   const double CAD = ca_x - ca_prod;
-  const double OC0 = wo * ((DOC_remin + S3) / REMIN_D_C_O2 + (2.0 * NITRIF));
+  const double OC0 = wo * (div_by(DOC_remin + S3, REMIN_D_C_O2, A.recip[R_REMIN]) + (2.0 * NITRIF));
 
   // ---- tendencies that do not see the particles (1703-1723) ----
   const double t_zooC = s_gr_zoo - zoo_loss;
@@ -860,7 +865,7 @@ __device__ __forceinline__ bool cell_body(const BgcKernelArgs& A, const obgc_bgc
     lo->S = r_salt; lo->zmid = zc; lo->PO4c = PO4; lo->SiO3c = SiO3;
     lo->prodPOC = prodPOC; lo->prodCa = prodCa; lo->prodSi = prodSi; lo->PfeLoc = PfeLoc;
     // what the walking wavefront would otherwise read from HBM again or compute at one lane per column
-    const LevelDerived dv = derive_level(P, zb, Tfunc, dmax(0.0, r_O2), dz);
+    const LevelDerived dv = derive_level(P, A.recip, zb, Tfunc, dmax(0.0, r_O2), dz);
     ho[H_DZ][tid] = dz; ho[H_ZB][tid] = zb; ho[H_FESED][tid] = r_fesed; ho[H_NO3][tid] = NO3; ho[H_FE][tid] = Fe; ho[H_O2][tid] = dmax(0.0, r_O2);
     ho[H_POC_DISS][tid] = dv.poc_diss; ho[H_SIO2_DISS][tid] = dv.sio2_diss; ho[H_CACO3_DISS][tid] = dv.caco3_diss;
     ho[H_DEC_POC][tid] = dv.decay_POC_E; ho[H_DEC_SI][tid] = dv.decay_SiO2; ho[H_DEC_CA][tid] = dv.decay_CaCO3;
@@ -1116,10 +1121,10 @@ __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obg
                SED_DENITRIF = o.SED_DENITRIF, OTHER_REMIN = o.OTHER_REMIN;
   // ---- denitrification (1569-1577) and the particle-dependent tendencies (1583-1790): the cell kernel
   //      left every local term in the tendency planes; only the remineralisation terms are added here ----
-  double wd = ((P.parm_o2_min + P.parm_o2_min_delta) - O2) / P.parm_o2_min_delta;
+  double wd = div_by((P.parm_o2_min + P.parm_o2_min_delta) - O2, P.parm_o2_min_delta, A.recip[R_O2DELTA]);
   wd = dmin(dmax(wd, 0.0), 1.0);
   if (NO3 == 0.0) wd = 0.0;
-  const double den_p = wd * ((reminPOC - OTHER_REMIN) / DENITRIF_C_N - SED_DENITRIF);
+  const double den_p = wd * (div_by(reminPOC - OTHER_REMIN, DENITRIF_C_N, A.recip[R_DENITRIF]) - SED_DENITRIF);
   const double t_no3 = (cur.L_no3 - den_p) - SED_DENITRIF;
   const double t_nh4 = cur.L_nh4 + QN * (reminPOC * (1.0 - DONREFRACT));
   const double t_fe = (reminFe + cur.L_fe) - Fe_scavenge;
@@ -1129,9 +1134,9 @@ __device__ __forceinline__ JTerms sweep_finish(const BgcKernelArgs& A, const obg
   const double t_dopr = cur.L_dopr + (reminPOC * DOPREFRACT * QP_ZOO_POM);
   const double t_dic = (cur.L_dic + reminPOC) + reminCa;
   const double t_alk = (-t_no3 + t_nh4 + 2.0 * reminCa) + cur.L_alk;
-  double wo = (O2 - P.parm_o2_min) / P.parm_o2_min_delta;
+  double wo = div_by(O2 - P.parm_o2_min, P.parm_o2_min_delta, A.recip[R_O2DELTA]);
   wo = dmin(dmax(wo, 0.0), 1.0);
-  const double oc_p = wo * ((reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN) / REMIN_D_C_O2);
+  const double oc_p = wo * div_by(reminPOC - (SED_DENITRIF * DENITRIF_C_N) - OTHER_REMIN, REMIN_D_C_O2, A.recip[R_REMIN]);
   OBGC_STORE(&TEND(P.ind[1], ix), Z(t_no3));
   OBGC_STORE(&TEND(P.ind[3], ix), Z(t_nh4));
   OBGC_STORE(&TEND(P.ind[4], ix), Z(t_fe));
@@ -1207,8 +1212,8 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
     if (k + 1 < kmax) load_level<DIAG>(A, P, g.at(k + 1, c), nxt);   // in flight while this level is evaluated
     // length scales and decay factors are functions of inputs this kernel reads anyway, so they are evaluated here
     // instead of travelling through HBM
-    const double TfuncS = exp((((cur.T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC)) / 10.0) * LN_Q_10);   // 1.5 ** (...)
-    const LevelDerived dv = derive_level(P, cur.zb, TfuncS, dmax(0.0, cur.O2), cur.dz);
+    const double TfuncS = exp(div_by((cur.T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC), 10.0, A.recip[R_TEN]) * LN_Q_10);   // 1.5 ** (...)
+    const LevelDerived dv = derive_level(P, A.recip, cur.zb, TfuncS, dmax(0.0, cur.O2), cur.dz);
     SweepCoreOut o;
     sweep_core(P, k == kmax - 1, cur.dz, cur.zb, cur.fesed, dmax(0.0, cur.NO3), dmax(0.0, cur.Fe), dmax(0.0, cur.O2), cur.prodPOC,
                cur.prodCa, cur.prodSi, cur.PfeLoc, dv, S, o);
@@ -1594,7 +1599,42 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
   }
 }
 
+// The divisor's share of a division, exactly as the compiler expands it in the kernels (Makefile, FASTDIV): hardware
+// reciprocal and two Newton steps.
+struct RecipIn { double y[R_N]; };
+__device__ double g_recip_out[R_N];
+__global__ void bgc_recip_kernel(const RecipIn in) {
+  const int i = threadIdx.x;
+  if (i >= (int)R_N) return;
+  const double y = in.y[i];
+  double r = __builtin_amdgcn_rcp(y);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  g_recip_out[i] = r;
+}
+
 }  // namespace
+
+hipError_t bgc_recips_compute(const obgc_bgc_params& P, double* recip_host, hipStream_t s) {
+  static std::mutex mu;   // one result array per device: handles that share a device take turns
+  std::lock_guard<std::mutex> lk(mu);
+  RecipIn in;
+  for (int i = 0; i < (int)R_N; ++i) in.y[i] = 1.0;
+  for (int a = 0; a < 4; ++a) {
+    const obgc_autotroph& t = P.autotrophs[a];
+    in.y[R_KNO3 + a] = t.kNO3; in.y[R_KNH4 + a] = t.kNH4; in.y[R_KPO4 + a] = t.kPO4; in.y[R_KDOP + a] = t.kDOP;
+    in.y[R_CKS_KFE + a] = CKS * t.kFe; in.y[R_CKSI_KSIO3 + a] = CKSI * t.kSiO3;   // the products as the kernels form them
+  }
+  in.y[R_RED] = RED_D_C_O2; in.y[R_REMIN] = REMIN_D_C_O2; in.y[R_RED_DIAZ] = RED_D_C_O2_DIAZ; in.y[R_DENITRIF] = DENITRIF_C_N;
+  in.y[R_O2DELTA] = P.parm_o2_min_delta; in.y[R_TEN] = 10.0; in.y[R_35] = 35.0; in.y[R_4E6] = 4.0e6; in.y[R_12E7] = 1.2e7;
+  for (int i = 0; i < 3; ++i) in.y[R_SCALELEN_DZ + i] = P.parm_scalelen_z[i + 1] - P.parm_scalelen_z[i];
+  hipLaunchKernelGGL(bgc_recip_kernel, dim3(1), dim3(64), 0, s, in);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  return hipMemcpyFromSymbol(recip_host, HIP_SYMBOL(g_recip_out), sizeof(double) * R_N);
+}
 
 void launch_bgc_att(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
   const long long ncell = (long long)a.g.nlev * a.g.ncol;

@@ -28,6 +28,8 @@ struct obgc_handle {
   int column = 1;  // OBGC_COLUMN_KERNEL=0: native-layout calls use the separate attenuation / scan / cell / sweep kernels (the form the
                    // reference layout always takes) instead of the column-block kernel
   obgc_bgc_params bgc;
+  double bgc_recip[40] = {};   // BgcKernelArgs::recip for `bgc`, computed on first use after the parameters change
+  bool bgc_recip_valid = false;
   obgc_dms_params dms;
   obgc_macros_params macros;
   // device scratch: one growing arena, carved per call

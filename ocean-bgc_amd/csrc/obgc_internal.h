@@ -91,7 +91,32 @@ struct BgcKernelArgs {
   obgc_bgc_diag diag;
   int have_diag;
   int alt_co2_use_eco;
+  double recip[40];   // refined reciprocals of the divisors every cell shares (RecipSlot, div_by)
 };
+
+// A cell's terms divide ~45 times by something every cell shares -- half-saturation constants, Redfield ratios, the width of
+// the O2 window.  The division as this library is compiled (reciprocal, two Newton steps, quotient, one correction) spends
+// five of its eight instructions on the divisor alone; for these divisors that part is done once per parameter set, on the
+// device, by the same instructions (bgc_recips_compute), and travels to the kernels in their arguments.  div_by finishes the
+// division with the remaining three: the same operations on the same values, hence the same bits.
+enum RecipSlot {
+  R_KNO3 = 0, R_KNH4 = 4, R_KPO4 = 8, R_KDOP = 12, R_CKS_KFE = 16, R_CKSI_KSIO3 = 20,   // + autotroph index
+  R_RED = 24, R_REMIN, R_RED_DIAZ, R_DENITRIF, R_O2DELTA, R_TEN, R_35, R_4E6, R_12E7,
+  R_SCALELEN_DZ,   // + 0..2: spacing of the length-scale table's depths
+  R_N = R_SCALELEN_DZ + 3
+};
+static_assert(R_N <= 40, "BgcKernelArgs::recip");
+__device__ __forceinline__ double div_by(double x, double y, double r) {
+#ifdef OBGC_IEEE_DIV
+  (void)r;
+  return x / y;
+#else
+  const double q = x * r;
+  return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+#endif
+}
+// host: the table for a parameter set, computed on the current device (synchronises `s`)
+hipError_t bgc_recips_compute(const obgc_bgc_params& P, double* recip_host, hipStream_t s);
 
 // DMS_SourceSink + MACROS_SourceSink folded into the BGC kernels (obgc_fused_step).  The tracers both modules share with
 // BGC are read from the BGC tracer array; only their own tracers, tendencies and diagnostics are separate planes in the

@@ -45,7 +45,7 @@ for tag in ("cfg4_full", "cfg4_none", "cfg2_full", "cfg2_none", "cfg4_full_colfa
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         m = re.search(r"(\w+_kernel)\b", r['Kernel_Name'].replace("(anonymous namespace)::", ""))
-        if m and m.group(1).startswith(("bgc_", "fused_", "dms_", "macros_")):
+        if m and m.group(1).startswith(("bgc_", "fused_", "dms_", "macros_")) and m.group(1) != "bgc_recip_kernel":
             acc[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
     run = {}
     for k, cs in acc.items():
