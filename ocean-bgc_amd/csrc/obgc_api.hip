@@ -119,6 +119,18 @@ bool grid_ok(const obgc_grid& g) {
   return true;
 }
 
+// Which kernel form a native-layout call takes.  A workgroup of the column-block kernel marches its 64 columns level by
+// level: ~17 us per chunk of four levels whatever the batch, 0.25-0.3 ms for 60 levels, with 32 of 256 CUs busy at 2 048
+// columns.  The separate kernels spread the cells of a small batch over the whole device and pay for it with hand-off
+// planes, which cost nothing at that size.  Measured at 60 levels with every diagnostic (without): 2 048 columns 0.25
+// against 0.44 ms (0.18 / 0.29), 8 192 columns 0.38 against 0.46 (0.24 / 0.30), 16 384 columns 0.59 against 0.55
+// (0.35 / 0.33): the column-block kernel from 700 000 cells.  The column-block layout always takes it.
+inline bool use_column_kernel(const obgc_handle* h, const GridView& v) {
+  if (v.tiled) return true;
+  if (h->column == 0 || v.kfast) return false;
+  return h->column >= 2 || (long long)v.nlev * v.ncol >= h->column_min_cells;
+}
+
 // The column-block layout is served by the column-block kernel (the carbonate solve inside it or in the carbonate kernel
 // beside it, as for the native layout) and the column integrals of the production profiles, which read the caller's own
 // photoC / photoC_NO3 / CaCO3_form / bSi_form.
@@ -321,6 +333,7 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
     if (hipEventCreate(e) != hipSuccess) { delete h; return OBGC_ERR_HIP; }
   if (const char* e = std::getenv("OBGC_SCHED")) h->sched = std::atoi(e);
   if (const char* e = std::getenv("OBGC_COLUMN_KERNEL")) h->column = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_COLUMN_MIN_CELLS")) h->column_min_cells = std::atoll(e);
   if (const char* e = std::getenv("OBGC_KFAST_HYBRID")) h->kfast_hybrid = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
   if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
@@ -891,7 +904,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   }
   obgc_bgc_diag wdiag0;                   // hybrid: the workspace owns every level-dependent plane it uses
   std::memset(&wdiag0, 0, sizeof wdiag0);
-  const bool column = !tiled && !v.kfast && h->column;   // generic strides (OBGC_KFAST_DIRECT=1) keep the separate kernels
+  const bool column = !tiled && use_column_kernel(h, v);   // generic strides (OBGC_KFAST_DIRECT=1) keep the separate kernels
   size_t scratch = bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, column);
   // the tile workspace runs whichever kernel form the handle selects: reserve for the larger of the two
   if (tiled && !hybrid) scratch = std::max(scratch, bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, h->column != 0));
@@ -1057,8 +1070,8 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   const bool want_zsat = b.diag && (b.diag->zsatcalc || b.diag->zsatarag);
   const size_t kc1 = span_kc(v, 1);
   // (the column-block kernel needs none of it: DMS's light runs through LDS beside BGC's)
-  const size_t dms_scratch = (a->dms && !h->column) ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
-  const bool column = h->column != 0;
+  const bool column = use_column_kernel(h, v);
+  const size_t dms_scratch = (a->dms && !column) ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
   int rc = arena_reserve(h, bgc_scratch_bytes(h, v, b.diag, want_zsat, false, column) + dms_scratch);
   if (rc != OBGC_OK) return rc;
 

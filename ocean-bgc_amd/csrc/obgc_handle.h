@@ -26,7 +26,9 @@ struct obgc_handle {
   int sched = -1;  // OBGC_SCHED: 0 carbonate from the start, 1 carbonate released after the cell kernel, 2 carbonate inside the cell kernel's
                    // wavefronts, -1 (default) = 1, or for batches of more than 10 M cells 2 with diagnostics and 0 without (see bgc_launch)
   int column = 1;  // OBGC_COLUMN_KERNEL=0: native-layout calls use the separate attenuation / scan / cell / sweep kernels (the form the
-                   // reference layout always takes) instead of the column-block kernel
+                   // reference layout always takes) instead of the column-block kernel; 2: the column-block kernel whatever the size
+  long long column_min_cells = 700000;   // OBGC_COLUMN_MIN_CELLS: native-layout calls below this many cells take the separate kernels
+                                         // (use_column_kernel)
   obgc_bgc_params bgc;
   double bgc_recip[40] = {};   // BgcKernelArgs::recip for `bgc`, computed on first use after the parameters change
   bool bgc_recip_valid = false;

@@ -11,6 +11,11 @@ import sys
 import numpy as np
 import pytest
 
+# The library takes the separate kernels for small native-layout batches (below 700 000 cells) and the column-block kernel
+# above; most tests here are small and are about the column-block kernel, so the suite lowers the threshold to zero.
+# tests/test_gpu_column_kernel.py::test_small_batches_take_the_separate_kernels_by_default covers the default.
+os.environ.setdefault("OBGC_COLUMN_MIN_CELLS", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -172,3 +172,35 @@ def test_garbage_below_the_sea_floor_changes_nothing(pkg, synth, monkeypatch, co
     for part in ("bgc", "dms", "macros"):
         _same(clean[part], got[part], "%s (column kernel %s)" % (part, column_kernel))
     assert np.isfinite(got["bgc"]["tend"]).all() and np.isfinite(got["dms"]["tend"]).all() and np.isfinite(got["macros"]["tend"]).all()
+
+
+def test_small_batches_take_the_separate_kernels_by_default(pkg, synth, monkeypatch):
+    """Without OBGC_COLUMN_MIN_CELLS (this suite sets it to 0) a native-layout call below 700 000 cells runs on the separate
+    kernels, which spread a small batch over the whole device, and a larger one on the column-block kernel; either way the
+    same bits, for BGC_SourceSink and for the fused step."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    from ocean_bgc_amd.modules import ColumnEngine
+    from oracle import fields as F
+    monkeypatch.delenv("OBGC_COLUMN_MIN_CELLS", raising=False)
+    monkeypatch.delenv("OBGC_COLUMN_KERNEL", raising=False)
+    auto = ColumnEngine(0, path="device_colfast")
+    monkeypatch.setenv("OBGC_COLUMN_KERNEL", "2")
+    forced = ColumnEngine(0, path="device_colfast")
+    for nc, nz, small in ((2_000, 60, True), (11_000, 64, False)):
+        syn = synth.generate(nc, nz, col0=9_000)
+        tr, dtr, mtr = synth.bgc_tracer_array(syn), synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)
+        args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+                syn["sw"])
+        z = np.zeros((nc, nz))
+        a = auto.BGC_SourceSink(*args, z, z, diag_init=-5.0)
+        assert (auto.eng.last_schedule() in (0, 1, 2)) == small and (auto.eng.last_schedule() in (3, 4)) == (not small)
+        b = forced.BGC_SourceSink(*args, z, z, diag_init=-5.0)
+        assert forced.eng.last_schedule() in (3, 4)
+        _same(a, b, "bgc %d" % nc)
+        sst = syn["forcing"]["SST"]
+        fa = auto.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0)
+        assert (auto.eng.last_schedule() in (0, 1, 2)) == small
+        fb = forced.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0)
+        for part in ("bgc", "dms", "macros"):
+            _same(fa[part], fb[part], "fused %s %d" % (part, nc))
