@@ -183,11 +183,13 @@ double obgc_last_kernel_ms(obgc_handle *h, int which);
  * start beside the ecosystem kernels, 1 it is released when the cell kernel ends, 2 the carbonate system is solved
  * inside the cell kernel's wavefronts (one launch for both); 3 the column-block kernel (light, cell terms, particle
  * recurrence AND the carbonate system in one launch: the native layout's default above 10 M cells with diagnostics),
- * 4 the column-block kernel with the carbonate kernel beside it (the native layout's default otherwise); -1 before
- * the first call.  Every arrangement gives the
+ * 4 the column-block kernel with the carbonate kernel beside it (the native layout's default otherwise, from 700 000
+ * cells per call; smaller native-layout calls take the separate kernels, schedules 0-2, which spread a small batch over
+ * the whole device); -1 before the first call.  Every arrangement gives the
  * same bits (measurement harnesses need to know which launch `which = 4` of obgc_last_kernel_ms timed).
- * Environment: OBGC_COLUMN_KERNEL=0 keeps the separate attenuation / scan / cell / sweep kernels (schedules 0-2),
- * OBGC_SCHED=<n> forces an arrangement. */
+ * Environment: OBGC_COLUMN_KERNEL=0 keeps the separate attenuation / scan / cell / sweep kernels (schedules 0-2) at every
+ * size, =2 the column-block kernel at every size; OBGC_COLUMN_MIN_CELLS=<n> moves the 700 000; OBGC_SCHED=<n> forces an
+ * arrangement. */
 int obgc_last_schedule(obgc_handle *h);
 
 /* --------------------------------------------------------- BGC_SourceSink */
