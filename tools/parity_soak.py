@@ -1,7 +1,8 @@
 # A wider net than the test-suite casts: GPU vs oracle over many blocks of synthetic columns (cold call, then a warm call on
 # perturbed tracers with the previous pH), 60, 80 and 100 levels, worst case per class.  The cold call is the fused
 # BGC + DMS + MACROS step (the headline path), the warm call BGC_SourceSink alone.  ~2 minutes for 8 blocks, mostly oracle time.
-# python tools/parity_soak.py [blocks]      (on an MI355X; the oracle only checks here)
+# python tools/parity_soak.py [blocks [path]]      (on an MI355X; the oracle only checks here; path = device_colfast (default:
+# blocks below 700 000 cells then run on the separate kernels, OBGC_COLUMN_KERNEL=2 forces the column-block kernel) or device_tiled)
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +14,7 @@ from ocean_bgc_amd import synth
 from ocean_bgc_amd.modules import ColumnEngine
 from oracle import orabind
 nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-E, O = ColumnEngine(0, path="device_colfast"), orabind.Oracle()
+E, O = ColumnEngine(0, path=sys.argv[2] if len(sys.argv) > 2 else "device_colfast"), orabind.Oracle()
 worst, bad = {}, 0
 for b in range(nblocks):
     nz = (60, 80, 100)[b % 3]
