@@ -198,24 +198,27 @@ class Workload:
         # the separate DMS / MACROS entry points keep scratch in the caller's index space: native layout only
         self.tiled = layout == "tiled" and (self.fused or not ("dms" in modules or "macros" in modules))
         # cold start per step: every timed step finds a zeroed pH pair of its own resident before the timed region when
-        # device memory allows (two planes per step); otherwise 8 pairs rotate and are cleared again inside the timing
+        # device memory allows (two planes per step, at most 64 pairs); otherwise as many pairs as fit rotate and are
+        # cleared again, by one fill, inside the timing
+        with_own = "dms" in modules or "macros" in modules or "dms_surf" in modules
+        with_dtr = ("dms" in modules or "dms_surf" in modules) and (not self.fused or "dms_surf" in modules)
+        # level-dependent planes of the workload without the pH pairs
+        nfixed = 30 + 6 + (5 if with_own else 0) + (14 if with_dtr else 0) + 30 + (5 if with_own else 0)
+        if not self.fused:
+            nfixed += (14 if "dms" in modules else 0) + (16 if "macros" in modules else 0)
+        if diag_on:
+            nfixed += len(L.BGC_DIAG_KC) - len(L.BGC_DIAG_KC_UNTOUCHED) + 4 * len(L.BGC_DIAG_KCA)
+            nfixed += (len(L.DMS_DIAG_KC) if "dms" in modules else 0) + (len(L.MACROS_DIAG_KC) if "macros" in modules else 0)
         self.nbuf = 1
         if ph != "warm":
             plane = ((ncol + 63) // 64) * 64 * nz * 8
-            n_base = 30 + 6 + 30 + 24 + (200 if diag_on else 0)
             free = torch.cuda.mem_get_info()[0]
-            self.nbuf = max(1, steps if (n_base + 2 * steps) * plane < 0.8 * free and steps <= 64 else min(steps, 8))
-        with_own = "dms" in modules or "macros" in modules or "dms_surf" in modules
-        with_dtr = ("dms" in modules or "dms_surf" in modules) and (not self.fused or "dms_surf" in modules)
+            fit = int((0.85 * free / plane - nfixed) // 2)       # pairs that fit beside the workload's own arrays
+            self.nbuf = max(1, min(steps, 64, max(fit, 8)))
         if self.tiled:
             # ONE arena for every level-dependent array: arena[block of 64 columns][level][row][64]; inputs first
             from ocean_bgc_amd.engine import TileArena
-            nrows = 30 + 6 + (5 if with_own else 0) + (14 if with_dtr else 0) + 30 + 2 * self.nbuf
-            if with_own:
-                nrows += 5
-            if diag_on:
-                nrows += len(L.BGC_DIAG_KC) - len(L.BGC_DIAG_KC_UNTOUCHED) + 4 * len(L.BGC_DIAG_KCA)
-                nrows += (len(L.DMS_DIAG_KC) if "dms" in modules else 0) + (len(L.MACROS_DIAG_KC) if "macros" in modules else 0)
+            nrows = nfixed + 2 * self.nbuf
             nrows += int(os.environ.get("OBGC_BENCH_TILE_PAD", "0"))      # experiment knob: unused rows at the end of every tile
             self.arena = TileArena(torch, dev, ncol, nz, nrows)
             KC = lambda n=1: self.arena.take(n, (ncol, nz) if n == 1 else None)
