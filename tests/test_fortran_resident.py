@@ -116,3 +116,17 @@ def test_fortran_resident_step_wall_time():
         assert m, txt
         print("\nFortran resident loop, 100000 x 60, fused=%d: first step %s ms, later steps %s ms" % (fused, m.group(1), m.group(2)))
         assert float(m.group(2)) < 15.0, txt
+
+
+@pytest.mark.parametrize("fused,nc,nz", [(0, 3_000, 60), (1, 2_029, 80)])
+def test_fortran_host_in_the_column_block_layout(tmp_path, pkg, fused, nc, nz):
+    """The same Fortran host with its level-dependent arrays as rows of one arena (OBGC_LAYOUT_TILED, module obgc_device with
+    tiled = .true.): three steps give the bits of the native layout, for BGC alone and for the fused step, also when the
+    column count is not a multiple of the 64-column block."""
+    out_n, out_t = str(tmp_path / "native.bin"), str(tmp_path / "tiled.bin")
+    _run(EXE_F, nc, nz, out_n, fused, 3, 0)
+    txt = _run(EXE_F, nc, nz, out_t, fused, 3, 1)
+    assert "tiled=1" in txt and re.search(r"schedule of the last source-sink call: [34]", txt), txt
+    a, b = np.fromfile(out_n, dtype=np.float64), np.fromfile(out_t, dtype=np.float64)
+    assert a.size == (35 if fused else 30) * nz * nc and np.isfinite(a).all()
+    assert np.array_equal(a, b)
