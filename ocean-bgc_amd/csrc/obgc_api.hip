@@ -384,8 +384,9 @@ extern "C" int obgc_set_bgc_params(obgc_handle* h, const obgc_bgc_params* p) {
     if (p->ind[i] < 1 || p->ind[i] > OBGC_BGC_NTRACER) return fail(h, OBGC_ERR_INVALID, "BGC tracer slot out of 1..30");
   if (p->lrest_po4 || p->lrest_no3 || p->lrest_sio3)
     return fail(h, OBGC_ERR_UNSUPPORTED, "nutrient restoring (lrest_*) is dead code in the reference and not provided");
+  // (the Fortran modules push their parameters before every call: the reciprocal table survives an unchanged set)
+  if (std::memcmp(&h->bgc, p, sizeof *p) != 0) h->bgc_recip_valid = false;
   h->bgc = *p;
-  h->bgc_recip_valid = false;
   return OBGC_OK;
 }
 extern "C" int obgc_set_dms_params(obgc_handle* h, const obgc_dms_params* p) {
