@@ -69,8 +69,11 @@ def test_engine_runs_from_a_parameter_file(gpu, synth, tmp_path):
     assert rep.ok(), "\n".join(rep.fail[:10])
     # the file made a difference: the default table gives other tendencies
     D = ColumnEngine(0, path="device_colfast")
-    assert not np.array_equal(D.BGC_SourceSink(*args, z, z, diagnostics=False)["tend"],
-                              E.BGC_SourceSink(*args, z, z, diagnostics=False)["tend"])
+    tuned = E.BGC_SourceSink(*args, z, z, diagnostics=False)["tend"]
+    assert not np.array_equal(D.BGC_SourceSink(*args, z, z, diagnostics=False)["tend"], tuned)
+    # ... and a handle that has already run follows a change of its table (what it derives from the table is redone)
+    D.bgc_set_params(p)
+    assert np.array_equal(D.BGC_SourceSink(*args, z, z, diagnostics=False)["tend"], tuned)
 
 
 def test_warm_step_resumed_from_a_restart_file_is_bit_identical(gpu, synth, tmp_path):
