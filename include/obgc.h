@@ -383,7 +383,7 @@ int obgc_apply_tendencies(obgc_handle *h, const obgc_apply_tendencies_args *a);
  * thickness up; thickness-weighted tendencies and surface fluxes down: 3.3 GB instead of 10 GB at 100k x 60), the
  * layout change and the unit conversions (m -> cm, rad -> deg, Pa -> atm, ...) run on the device, and the path itself
  * runs in its native column-fastest layout.  Same arithmetic as the Fortran adapter, so both give the same bits.
- * All pointers are HOST pointers in the model's layout. */
+ * obgc_block_step takes HOST pointers in the model's layout, obgc_block_step_device DEVICE pointers in the same layout. */
 typedef struct obgc_block obgc_block;
 int obgc_block_create(obgc_handle *h, int nCells, int nVertLevels, obgc_block **out);
 int obgc_block_destroy(obgc_block *b);
@@ -419,6 +419,16 @@ typedef struct {
 /* one BGC_SurfaceFluxes + BGC_SourceSink over the whole block (tendencies only; PH_PREV_* and surface_pH* persist
  * inside the block); with dmsTracers / macrosTracers also DMS_SurfaceFluxes and the fused BGC + DMS + MACROS step */
 int obgc_block_step(obgc_block *b, const obgc_block_step_args *a);
+
+/* The same step for a model whose arrays already live on the handle's GPU (an OpenACC / OpenMP-offloaded or HIP ocean
+ * model): every pointer of obgc_block_step_args is a DEVICE pointer, in the same tracer-fastest layout and units.  The
+ * layout change reads the model's arrays and writes (or adds to) its tendency and flux arrays directly: nothing is staged,
+ * nothing crosses PCIe, and a block that is only ever stepped this way reserves no staging memory.  The model's arrays
+ * are not modified apart from the outputs (the package's in-place Fe scaling of the flux arrays works on copies).
+ * Same kernels and arithmetic as obgc_block_step: same bits.  Runs on the handle's stream; returns after enqueue on a
+ * handle created with OBGC_ASYNC (obgc_sync completes it), after completion otherwise.  The two forms may be mixed on
+ * one block. */
+int obgc_block_step_device(obgc_block *b, const obgc_block_step_args *a);
 
 /* --------------------------------------- diagnostics kept on the device
  * NO reference counterpart (the host model averages and writes diagnostics).  Diagnostics are 65 % of the bytes

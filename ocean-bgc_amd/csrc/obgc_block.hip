@@ -14,15 +14,15 @@
 struct obgc_block {
   obgc_handle* h = nullptr;
   int nc = 0, nz = 0;
-  char* pool = nullptr;      // one device allocation
+  char* pool = nullptr;      // one device allocation: the native state
+  char* pool_m = nullptr;    // staging of host arrays, reserved by the first step that is given host pointers
   // native (column-fastest) state
   double *tracers, *temp, *salt, *zmid, *dz, *zbot, *fesed, *tend, *php, *pha;
   double *lat, *dust, *sw, *patm, *ice, *wind, *co2, *co2alt, *sph, *spha, *sdepth, *sst, *sss;
   double *depo, *river, *gas, *seaice, *net;
   int* kmax;
   // staging of the model's arrays (model layout)
-  double *m_tr, *m_h, *m_zmid, *m_t, *m_s, *m_fesed, *m_tend, *m_sflux, *m_c[8], *m_flux[3];
-  int* m_kmax;
+  double *m_tr = nullptr, *m_h, *m_zmid, *m_t, *m_s, *m_fesed, *m_tend, *m_sflux, *m_c[8];
   // pipelined step: cell chunks, results of chunk i go down on s_down while chunk i+1 comes up on the engine's stream
   enum { kMaxChunks = 16 };
   int chunks = 8, min_cells = 8192, threads = 1;   // OBGC_HOST_THREADS=0: downloads in line
@@ -185,12 +185,6 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
     want((void**)p, nc * d);
   for (double** p : {&b->depo, &b->river, &b->gas, &b->seaice, &b->net}) want((void**)p, NT * nc * d);
   want((void**)&b->kmax, nc * sizeof(int));
-  want((void**)&b->m_tr, NT * kc * d); want((void**)&b->m_tend, NT * kc * d);
-  for (double** p : {&b->m_h, &b->m_zmid, &b->m_t, &b->m_s, &b->m_fesed}) want((void**)p, kc * d);
-  for (int i = 0; i < 8; ++i) want((void**)&b->m_c[i], nc * d);
-  for (int i = 0; i < 3; ++i) want((void**)&b->m_flux[i], NT * nc * d);
-  want((void**)&b->m_sflux, NT * nc * d);
-  want((void**)&b->m_kmax, nc * sizeof(int));
   if (hipMalloc((void**)&b->pool, total) != hipSuccess) { delete b; return OBGC_ERR_ALLOC; }
   for (auto& s : slots) *s.first = b->pool + s.second;
   hipStream_t st = (hipStream_t)obgc_stream(h);
@@ -218,12 +212,30 @@ extern "C" int obgc_block_destroy(obgc_block* b) {
   if (b->s_down) (void)hipStreamDestroy(b->s_down);
   for (hipEvent_t e : b->ev_done) if (e) (void)hipEventDestroy(e);
   (void)hipFree(b->pool);
+  if (b->pool_m) (void)hipFree(b->pool_m);
   if (b->pool2) (void)hipFree(b->pool2);
   delete b;
   return OBGC_OK;
 }
 
 namespace {
+
+// device copies of the model's own arrays, for steps that are given host pointers (the first such step reserves them; a
+// block that only ever sees device pointers never does)
+int block_reserve_staging(obgc_block* b) {
+  if (b->pool_m) return OBGC_OK;
+  const size_t nc = (size_t)b->nc, kc = nc * (size_t)b->nz, d = sizeof(double), al = 256;
+  size_t total = 0;
+  std::vector<std::pair<void**, size_t>> slots;
+  auto want = [&](void** p, size_t bytes) { slots.push_back({p, total}); total += (bytes + al - 1) / al * al; };
+  want((void**)&b->m_tr, NT * kc * d); want((void**)&b->m_tend, NT * kc * d);
+  for (double** p : {&b->m_h, &b->m_zmid, &b->m_t, &b->m_s, &b->m_fesed}) want((void**)p, kc * d);
+  for (int i = 0; i < 8; ++i) want((void**)&b->m_c[i], nc * d);
+  want((void**)&b->m_sflux, NT * nc * d);
+  if (hipMalloc((void**)&b->pool_m, total) != hipSuccess) return OBGC_ERR_ALLOC;
+  for (auto& s : slots) *s.first = b->pool_m + s.second;
+  return OBGC_OK;
+}
 
 // device room for DMS / MACROS on the block, on the first step that runs them
 int block_reserve_own(obgc_block* b) {
@@ -244,43 +256,69 @@ int block_reserve_own(obgc_block* b) {
   return OBGC_OK;
 }
 
-// cells [c0, c1) of the block: upload their slices, pack, BGC_SurfaceFluxes + BGC_SourceSink on the native arrays (a
-// column range of a column-fastest array is the same array with an offset and the block's row stride), unpack
-int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c1) {
+// Where one step reads the model's arrays and writes its results: the block's staging copies (host pointers came in) or
+// the caller's own device arrays (device pointers came in: nothing is staged, the pack / unpack kernels work on them directly).
+struct ModelArrays {
+  const double *tr, *h, *zmid, *t, *s, *fesed, *c[8], *own[2];
+  const int* kmax;
+  double *tend, *sflux, *own_tend[2], *dms_sflux;
+};
+
+ModelArrays model_arrays(const obgc_block* b, const obgc_block_step_args* a, bool dev) {
+  ModelArrays m;
+  const double* cols[8] = {a->latCell, a->shortWaveHeatFlux, a->atmosphericPressure, a->iceFraction, a->windSpeedSquared10m,
+                           a->atmosphericCO2, a->atmosphericCO2_ALT_CO2, a->dustFlux};
+  m.tr = dev ? a->ecosysTracers : b->m_tr; m.h = dev ? a->layerThickness : b->m_h; m.zmid = dev ? a->zMid : b->m_zmid;
+  m.t = dev ? a->temperature : b->m_t; m.s = dev ? a->salinity : b->m_s; m.fesed = dev ? a->ironSedimentFlux : b->m_fesed;
+  for (int i = 0; i < 8; ++i) m.c[i] = dev ? cols[i] : b->m_c[i];
+  m.own[0] = dev ? a->dmsTracers : b->m_own[0]; m.own[1] = dev ? a->macrosTracers : b->m_own[1];
+  m.kmax = dev ? a->maxLevelCell : b->kmax;
+  m.tend = dev ? a->ecosysTracersTend : b->m_tend; m.sflux = dev ? a->ecosysSurfaceFlux : b->m_sflux;
+  m.own_tend[0] = dev ? a->dmsTracersTend : b->m_own_tend[0]; m.own_tend[1] = dev ? a->macrosTracersTend : b->m_own_tend[1];
+  m.dms_sflux = dev ? a->dmsSurfaceFlux : b->m_dms_sflux;
+  return m;
+}
+
+// cells [c0, c1) of the block: upload their slices (host pointers), pack, BGC_SurfaceFluxes + BGC_SourceSink on the native
+// arrays (a column range of a column-fastest array is the same array with an offset and the block's row stride), unpack
+int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c1, bool dev) {
   const int ncb = b->nc, nz = b->nz, n = c1 - c0;
   const size_t d = sizeof(double);
   const size_t kc0 = (size_t)c0 * nz, kcn = (size_t)n * nz;
   hipStream_t st = (hipStream_t)obgc_stream(b->h);
-#define UP(dst, src, bytes) if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return OBGC_ERR_HIP;
-  UP(b->m_tr + NT * kc0, a->ecosysTracers + NT * kc0, NT * kcn * d)
-  UP(b->m_h + kc0, a->layerThickness + kc0, kcn * d) UP(b->m_zmid + kc0, a->zMid + kc0, kcn * d)
-  UP(b->m_t + kc0, a->temperature + kc0, kcn * d) UP(b->m_s + kc0, a->salinity + kc0, kcn * d)
-  UP(b->m_fesed + kc0, a->ironSedimentFlux + kc0, kcn * d)
-  if (a->accumulate) UP(b->m_tend + NT * kc0, a->ecosysTracersTend + NT * kc0, NT * kcn * d)
   const bool with_dms = a->dmsTracers != nullptr, with_macros = a->macrosTracers != nullptr;
-  if (with_dms) {
-    UP(b->m_own[0] + 2 * kc0, a->dmsTracers + 2 * kc0, 2 * kcn * d)
-    if (a->accumulate) UP(b->m_own_tend[0] + 2 * kc0, a->dmsTracersTend + 2 * kc0, 2 * kcn * d)
-  }
-  if (with_macros) {
-    UP(b->m_own[1] + 3 * kc0, a->macrosTracers + 3 * kc0, 3 * kcn * d)
-    if (a->accumulate) UP(b->m_own_tend[1] + 3 * kc0, a->macrosTracersTend + 3 * kc0, 3 * kcn * d)
-  }
+  const ModelArrays m = model_arrays(b, a, dev);
+  if (!dev) {
+#define UP(dst, src, bytes) if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return OBGC_ERR_HIP;
+    UP(b->m_tr + NT * kc0, a->ecosysTracers + NT * kc0, NT * kcn * d)
+    UP(b->m_h + kc0, a->layerThickness + kc0, kcn * d) UP(b->m_zmid + kc0, a->zMid + kc0, kcn * d)
+    UP(b->m_t + kc0, a->temperature + kc0, kcn * d) UP(b->m_s + kc0, a->salinity + kc0, kcn * d)
+    UP(b->m_fesed + kc0, a->ironSedimentFlux + kc0, kcn * d)
+    if (a->accumulate) UP(b->m_tend + NT * kc0, a->ecosysTracersTend + NT * kc0, NT * kcn * d)
+    if (with_dms) {
+      UP(b->m_own[0] + 2 * kc0, a->dmsTracers + 2 * kc0, 2 * kcn * d)
+      if (a->accumulate) UP(b->m_own_tend[0] + 2 * kc0, a->dmsTracersTend + 2 * kc0, 2 * kcn * d)
+    }
+    if (with_macros) {
+      UP(b->m_own[1] + 3 * kc0, a->macrosTracers + 3 * kc0, 3 * kcn * d)
+      if (a->accumulate) UP(b->m_own_tend[1] + 3 * kc0, a->macrosTracersTend + 3 * kc0, 3 * kcn * d)
+    }
 #undef UP
+  }
   const long long plane = (long long)ncb * nz;
   if (with_dms)
-    hipLaunchKernelGGL(block_pack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->m_own[0] + 2 * kc0, b->own + c0, nz, n,
+    hipLaunchKernelGGL(block_pack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, m.own[0] + 2 * kc0, b->own + c0, nz, n,
                        (long long)ncb, 2);
   if (with_macros)
-    hipLaunchKernelGGL(block_pack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->m_own[1] + 3 * kc0, b->own + 2 * plane + c0,
+    hipLaunchKernelGGL(block_pack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, m.own[1] + 3 * kc0, b->own + 2 * plane + c0,
                        nz, n, (long long)ncb, 3);
-  hipLaunchKernelGGL(block_pack_tracers_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->m_tr + NT * kc0, b->tracers + c0, nz, n,
+  hipLaunchKernelGGL(block_pack_tracers_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, m.tr + NT * kc0, b->tracers + c0, nz, n,
                      (long long)ncb);
   PackArgs pa;
   pa.nz = nz; pa.nc = n; pa.ld = ncb;
-  pa.h = b->m_h + kc0; pa.zmid = b->m_zmid + kc0; pa.t = b->m_t + kc0; pa.s = b->m_s + kc0; pa.fesed = b->m_fesed + kc0;
-  pa.lat = b->m_c[0] + c0; pa.swf = b->m_c[1] + c0; pa.patm = b->m_c[2] + c0; pa.ice = b->m_c[3] + c0; pa.wind = b->m_c[4] + c0;
-  pa.co2 = b->m_c[5] + c0; pa.co2alt = b->m_c[6] + c0; pa.dustf = b->m_c[7] + c0;
+  pa.h = m.h + kc0; pa.zmid = m.zmid + kc0; pa.t = m.t + kc0; pa.s = m.s + kc0; pa.fesed = m.fesed + kc0;
+  pa.lat = m.c[0] + c0; pa.swf = m.c[1] + c0; pa.patm = m.c[2] + c0; pa.ice = m.c[3] + c0; pa.wind = m.c[4] + c0;
+  pa.co2 = m.c[5] + c0; pa.co2alt = m.c[6] + c0; pa.dustf = m.c[7] + c0;
   pa.dz = b->dz + c0; pa.o_zmid = b->zmid + c0; pa.zbot = b->zbot + c0; pa.o_t = b->temp + c0; pa.o_s = b->salt + c0;
   pa.o_fesed = b->fesed + c0;
   pa.o_lat = b->lat + c0; pa.o_sw = b->sw + c0; pa.o_patm = b->patm + c0; pa.o_ice = b->ice + c0; pa.o_wind = b->wind + c0;
@@ -309,7 +347,7 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
   std::memset(&ss, 0, sizeof ss);
   ss.grid = g; ss.tracers = b->tracers + c0; ss.temp = b->temp + c0; ss.salt = b->salt + c0; ss.zmid = b->zmid + c0;
   ss.dz = b->dz + c0; ss.zbot = b->zbot + c0;
-  ss.lat = b->lat + c0; ss.kmax = b->kmax + c0; ss.fesedflux = b->fesed + c0; ss.dust_flux_in = b->dust + c0; ss.sw_flux = b->sw + c0;
+  ss.lat = b->lat + c0; ss.kmax = m.kmax + c0; ss.fesedflux = b->fesed + c0; ss.dust_flux_in = b->dust + c0; ss.sw_flux = b->sw + c0;
   ss.tend = b->tend + c0; ss.ph_prev = b->php + c0; ss.ph_prev_alt = b->pha + c0; ss.diag = nullptr; ss.alt_co2_use_eco = 0;
   if (with_dms) {
     // DMS_SurfaceFluxes reads the surface row of ONE tracer (DMS_mod.F90:834): a one-level 14-plane array holds it
@@ -324,7 +362,7 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
     ds.iceFraction = b->ice + c0; ds.netFlux = b->dms_net + c0; ds.lcalc_DMS_gas_flux = 1;
     rc = obgc_dms_surface_fluxes(b->h, &ds);
     if (rc != OBGC_OK) return rc;
-    hipLaunchKernelGGL(block_dms_sflux_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b->dms_net + c0, b->m_dms_sflux + 2 * (size_t)c0, n,
+    hipLaunchKernelGGL(block_dms_sflux_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b->dms_net + c0, m.dms_sflux + 2 * (size_t)c0, n,
                        (long long)ncb, dp.ind[0], dp.ind[1]);
   }
   if (with_dms || with_macros) {
@@ -345,16 +383,16 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
   }
   if (rc != OBGC_OK) return rc;
   if (with_dms)
-    hipLaunchKernelGGL(block_unpack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->own_tend + c0, b->m_h + kc0, b->kmax + c0,
-                       b->m_own_tend[0] + 2 * kc0, nz, n, (long long)ncb, 2, a->accumulate ? 1 : 0);
+    hipLaunchKernelGGL(block_unpack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->own_tend + c0, m.h + kc0, m.kmax + c0,
+                       m.own_tend[0] + 2 * kc0, nz, n, (long long)ncb, 2, a->accumulate ? 1 : 0);
   if (with_macros)
-    hipLaunchKernelGGL(block_unpack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->own_tend + 2 * plane + c0, b->m_h + kc0,
-                       b->kmax + c0, b->m_own_tend[1] + 3 * kc0, nz, n, (long long)ncb, 3, a->accumulate ? 1 : 0);
+    hipLaunchKernelGGL(block_unpack_small_kernel, dim3((n + 255) / 256, nz), dim3(256), 0, st, b->own_tend + 2 * plane + c0, m.h + kc0,
+                       m.kmax + c0, m.own_tend[1] + 3 * kc0, nz, n, (long long)ncb, 3, a->accumulate ? 1 : 0);
 
-  hipLaunchKernelGGL(block_unpack_tend_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->tend + c0, b->m_h + kc0, b->kmax + c0,
-                     b->m_tend + NT * kc0, nz, n, (long long)ncb, a->accumulate ? 1 : 0);
+  hipLaunchKernelGGL(block_unpack_tend_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, b->tend + c0, m.h + kc0, m.kmax + c0,
+                     m.tend + NT * kc0, nz, n, (long long)ncb, a->accumulate ? 1 : 0);
   hipLaunchKernelGGL(block_sflux_kernel, dim3((unsigned)(((long long)n * NT + 255) / 256)), dim3(256), 0, st, b->net + c0,
-                     b->m_sflux + (size_t)NT * c0, n, (long long)ncb);
+                     m.sflux + (size_t)NT * c0, n, (long long)ncb);
   return hipGetLastError() == hipSuccess ? OBGC_OK : OBGC_ERR_HIP;
 }
 
@@ -374,6 +412,15 @@ hipError_t block_download_range(obgc_block* b, const obgc_block_step_args* a, in
   return e;
 }
 
+bool block_args_complete(const obgc_block_step_args* a) {
+  if (!a->ecosysTracers || !a->layerThickness || !a->zMid || !a->temperature || !a->salinity || !a->maxLevelCell || !a->latCell ||
+      !a->shortWaveHeatFlux || !a->atmosphericPressure || !a->iceFraction || !a->windSpeedSquared10m || !a->atmosphericCO2 ||
+      !a->atmosphericCO2_ALT_CO2 || !a->dustFlux || !a->ironSedimentFlux || !a->depositionFlux || !a->riverFlux || !a->seaIceFlux ||
+      !a->ecosysTracersTend || !a->ecosysSurfaceFlux)
+    return false;
+  return !((a->dmsTracers && (!a->dmsTracersTend || !a->dmsSurfaceFlux)) || (a->macrosTracers && !a->macrosTracersTend));
+}
+
 }  // namespace
 
 // The step is bound by the link (1.7 GB up, 1.4 GB down at 100k x 60 against 2.5 ms of kernels): cells are independent,
@@ -381,16 +428,15 @@ hipError_t block_download_range(obgc_block* b, const obgc_block_step_args* a, in
 // second thread sends the results of range i down while this one brings range i+1 up.
 extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   if (!b || !a) return OBGC_ERR_INVALID;
-  if (!a->ecosysTracers || !a->layerThickness || !a->zMid || !a->temperature || !a->salinity || !a->maxLevelCell || !a->latCell ||
-      !a->shortWaveHeatFlux || !a->atmosphericPressure || !a->iceFraction || !a->windSpeedSquared10m || !a->atmosphericCO2 ||
-      !a->atmosphericCO2_ALT_CO2 || !a->dustFlux || !a->ironSedimentFlux || !a->depositionFlux || !a->riverFlux || !a->seaIceFlux ||
-      !a->ecosysTracersTend || !a->ecosysSurfaceFlux)
-    return OBGC_ERR_INVALID;
-  if ((a->dmsTracers && (!a->dmsTracersTend || !a->dmsSurfaceFlux)) || (a->macrosTracers && !a->macrosTracersTend)) return OBGC_ERR_INVALID;
+  if (!block_args_complete(a)) return OBGC_ERR_INVALID;
   const int nc = b->nc;
   const size_t d = sizeof(double);
   const int device = handle_device(b->h);
   if (hipSetDevice(device) != hipSuccess) return OBGC_ERR_HIP;   // the calling thread's current device may be another GPU
+  {
+    const int rc1 = block_reserve_staging(b);
+    if (rc1 != OBGC_OK) return rc1;
+  }
   if (a->dmsTracers || a->macrosTracers) {
     const int rc2 = block_reserve_own(b);
     if (rc2 != OBGC_OK) return rc2;
@@ -410,7 +456,7 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   int chunk = ((nc + nchunk - 1) / nchunk + 63) / 64 * 64;
   nchunk = (nc + chunk - 1) / chunk;
   if (nchunk == 1) {
-    int rc = block_step_range(b, a, 0, nc);
+    int rc = block_step_range(b, a, 0, nc, false);
     if (rc != OBGC_OK) return rc;
     if (block_download_range(b, a, 0, nc, st) != hipSuccess) return OBGC_ERR_HIP;
     return hipStreamSynchronize(st) == hipSuccess ? OBGC_OK : OBGC_ERR_HIP;
@@ -445,7 +491,7 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   int rc = OBGC_OK;
   for (int i = 0; i < nchunk && rc == OBGC_OK; ++i) {
     const int c0 = i * chunk, c1 = (c0 + chunk < nc) ? c0 + chunk : nc;
-    rc = block_step_range(b, a, c0, c1);
+    rc = block_step_range(b, a, c0, c1, false);
     if (rc == OBGC_OK && hipEventRecord(b->ev_done[i], st) != hipSuccess) rc = OBGC_ERR_HIP;
     if (rc != OBGC_OK) break;
     if (!threaded) {
@@ -467,4 +513,28 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
   if (hipStreamSynchronize(st) != hipSuccess && rc == OBGC_OK) rc = OBGC_ERR_HIP;
   if (rc == OBGC_OK && down_err != hipSuccess) rc = OBGC_ERR_HIP;
   return rc;
+}
+
+// The same step for a model whose arrays already live on this GPU: the pack kernels read the caller's arrays, the unpack
+// kernels write (or add to) the caller's tendency and flux arrays; nothing is staged and nothing crosses the link.
+extern "C" int obgc_block_step_device(obgc_block* b, const obgc_block_step_args* a) {
+  if (!b || !a) return OBGC_ERR_INVALID;
+  if (!block_args_complete(a)) return OBGC_ERR_INVALID;
+  const int nc = b->nc;
+  const size_t d = sizeof(double);
+  if (hipSetDevice(handle_device(b->h)) != hipSuccess) return OBGC_ERR_HIP;
+  if (a->dmsTracers || a->macrosTracers) {
+    const int rc2 = block_reserve_own(b);
+    if (rc2 != OBGC_OK) return rc2;
+  }
+  hipStream_t st = (hipStream_t)obgc_stream(b->h);
+  // the package scales the Fe rows of the three flux arrays in place: it works on copies, the caller's stay as they are
+  const double* src[3] = {a->depositionFlux, a->riverFlux, a->seaIceFlux};
+  double* dst[3] = {b->depo, b->river, b->seaice};
+  for (int i = 0; i < 3; ++i)
+    if (hipMemcpyAsync(dst[i], src[i], NT * (size_t)nc * d, hipMemcpyDeviceToDevice, st) != hipSuccess) return OBGC_ERR_HIP;
+  const int rc = block_step_range(b, a, 0, nc, true);
+  if (rc != OBGC_OK) return rc;
+  if (b->h->flags & OBGC_ASYNC) return OBGC_OK;
+  return hipStreamSynchronize(st) == hipSuccess ? OBGC_OK : OBGC_ERR_HIP;
 }

@@ -318,3 +318,84 @@ def test_resident_block_with_dms_and_macros_in_the_fused_step(synth, oracle, pkg
     assert np.array_equal(a30, np.where(active, 5.0 + o30, 5.0))
     assert np.array_equal(a2, np.where(active, 5.0 + o2, 5.0)) and np.array_equal(a3, np.where(active, 5.0 + o3, 5.0))
     assert E.lib.obgc_block_destroy(blk) == 0 and E.lib.obgc_block_destroy(blk0) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_own", [False, True])
+def test_resident_block_device_pointers_same_bits_as_host_pointers(synth, pkg, monkeypatch, with_own):
+    """A model whose arrays already live on the GPU: obgc_block_step_device on device copies of the model's arrays gives the
+    bits of obgc_block_step on the host arrays -- overwrite, a warm second step that accumulates, with and without the own
+    tracers of DMS and MACROS -- and leaves every input array as it was (the package's in-place Fe scaling of the flux
+    arrays included)."""
+    import ctypes as C
+    import torch
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    monkeypatch.setenv("OBGC_BLOCK_CHUNKS", "1")
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    nc, nz = 700, 60                                        # not a multiple of 64: ragged last workgroup of every kernel
+    m, pk = mpas_block(synth, nc, nz, col0=120000)
+    syn = synth.generate(nc, nz, col0=120000)
+    own_d = np.ascontiguousarray(synth.dms_tracer_array(syn)[0:2].transpose(1, 2, 0))
+    own_m = np.ascontiguousarray(synth.macros_tracer_array(syn)[0:3].transpose(1, 2, 0))
+    E = Engine(0)
+    blk_h, blk_d = C.c_void_p(), C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk_h)) == 0 and E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk_d)) == 0
+    dev = torch.device("cuda:0")
+
+    def host_step(tend, dtend, mtend, accumulate):
+        a, keep, sflux = block_args(L, m, nc, nz, tend, accumulate)
+        dsf = np.full((nc, 2), -9.0)
+        if with_own:
+            a.dmsTracers = own_d.ctypes.data_as(C.c_void_p); a.dmsTracersTend = dtend.ctypes.data_as(C.c_void_p)
+            a.dmsSurfaceFlux = dsf.ctypes.data_as(C.c_void_p)
+            a.macrosTracers = own_m.ctypes.data_as(C.c_void_p); a.macrosTracersTend = mtend.ctypes.data_as(C.c_void_p)
+        rc = E.lib.obgc_block_step(blk_h, C.byref(a))
+        assert rc == 0, (rc, E.lib.obgc_last_error(E.h))
+        return sflux, dsf
+
+    def device_step(tend, dtend, mtend, accumulate):
+        a, keep, _ = block_args(L, m, nc, nz, tend, accumulate)
+        names = [n for n, _t in L.BlockStepArgs._fields_ if n not in ("accumulate",)]
+        host = {"ecosysTracersTend": tend, "ecosysSurfaceFlux": np.full((nc, 30), -9.0)}
+        if with_own:
+            host.update(dmsTracers=own_d, dmsTracersTend=dtend, dmsSurfaceFlux=np.full((nc, 2), -9.0), macrosTracers=own_m,
+                        macrosTracersTend=mtend)
+        # every array the struct points to, as a device tensor of the same bytes
+        by_addr = {x.ctypes.data: x for x in keep}
+        t = {}
+        for n in names:
+            if n in host:
+                src = host[n]
+            else:
+                addr = getattr(a, n)
+                if not addr:
+                    continue
+                src = by_addr[addr]
+            t[n] = torch.from_numpy(src).to(dev)
+            setattr(a, n, C.c_void_p(t[n].data_ptr()))
+        before = {n: x.clone() for n, x in t.items()}
+        torch.cuda.synchronize()
+        rc = E.lib.obgc_block_step_device(blk_d, C.byref(a))
+        assert rc == 0, (rc, E.lib.obgc_last_error(E.h))
+        torch.cuda.synchronize()
+        outs = ("ecosysTracersTend", "ecosysSurfaceFlux", "dmsTracersTend", "dmsSurfaceFlux", "macrosTracersTend")
+        for n in t:
+            if n not in outs:
+                assert torch.equal(t[n], before[n]), n + " was modified"
+        tend[:] = t["ecosysTracersTend"].cpu().numpy()
+        if with_own:
+            dtend[:] = t["dmsTracersTend"].cpu().numpy(); mtend[:] = t["macrosTracersTend"].cpu().numpy()
+        return t["ecosysSurfaceFlux"].cpu().numpy(), (t["dmsSurfaceFlux"].cpu().numpy() if with_own else None)
+
+    for accumulate, fill in ((False, 123.0), (True, 5.0)):
+        th, dh, mh = np.full((nc, nz, 30), fill), np.full((nc, nz, 2), fill), np.full((nc, nz, 3), fill)
+        td, dd, md = th.copy(), dh.copy(), mh.copy()
+        sf_h, dsf_h = host_step(th, dh, mh, accumulate)
+        sf_d, dsf_d = device_step(td, dd, md, accumulate)
+        assert np.array_equal(th, td) and np.array_equal(sf_h, sf_d)
+        assert np.abs(th).max() > 0 and not np.array_equal(th, np.full_like(th, fill))
+        if with_own:
+            assert np.array_equal(dh, dd) and np.array_equal(mh, md) and np.array_equal(dsf_h, dsf_d)
+    assert E.lib.obgc_block_destroy(blk_h) == 0 and E.lib.obgc_block_destroy(blk_d) == 0

@@ -42,3 +42,34 @@ for i in range(5):
     ts.append(time.perf_counter() - t0)
 print("resident block step with DMS + MACROS (fused): best %.1f ms -> %.3e updates/s (PCIe-inclusive)"
       % (1e3 * min(ts[1:]), 35 * cells / min(ts[1:])), flush=True)
+
+# the same steps for a model whose arrays already live on the GPU (obgc_block_step_device): no link in the step at all
+import torch
+dev = torch.device("cuda:0")
+host = {"ecosysTracersTend": tend, "ecosysSurfaceFlux": sflux, "dmsTracers": own_d, "dmsTracersTend": dtend, "dmsSurfaceFlux": dsf,
+        "macrosTracers": own_m, "macrosTracersTend": mtend}
+by_addr = {x.ctypes.data: x for x in keep}
+own_names = ("dmsTracers", "dmsTracersTend", "dmsSurfaceFlux", "macrosTracers", "macrosTracersTend")
+for with_own in (False, True):
+    b2 = C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(b2)) == 0
+    t = {}
+    d = L.BlockStepArgs()
+    for n, _t in L.BlockStepArgs._fields_:
+        if n == "accumulate" or (n in own_names and not with_own):
+            continue
+        src = host[n] if n in host else by_addr[getattr(a, n)]
+        t[n] = torch.from_numpy(src).to(dev)
+        setattr(d, n, C.c_void_p(t[n].data_ptr()))
+    for acc in (False, True):
+        d.accumulate = 1 if acc else 0
+        ts = []
+        for i in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            assert E.lib.obgc_block_step_device(b2, C.byref(d)) == 0
+            ts.append(time.perf_counter() - t0)
+        print("device-pointer block step%s, accumulate=%s: best %.2f ms -> %.3e updates/s"
+              % (" with DMS + MACROS (fused)" if with_own else "", acc, 1e3 * min(ts[1:]), (35 if with_own else 30) * cells / min(ts[1:])),
+              flush=True)
+    assert E.lib.obgc_block_destroy(b2) == 0
