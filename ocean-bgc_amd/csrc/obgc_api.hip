@@ -1105,8 +1105,7 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
       return p;
     };
     F.d_att = (double*)carve(kc1); F.d_kpardz = (double*)carve(kc1); F.d_parin = (double*)carve(kc1);
-    F.flag = (int*)carve((size_t)v.ncol * sizeof(int));
-    HIP_TRY(h, hipMemsetAsync(F.flag, 0, (size_t)v.ncol * sizeof(int), h->s_main));
+    F.flag = (int*)carve((size_t)v.ncol * sizeof(int));   // cleared by the first kernel of the launch set
   }
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
   rc = bgc_launch(h, K, want_zsat, &F);

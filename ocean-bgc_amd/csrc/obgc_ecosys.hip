@@ -1670,10 +1670,17 @@ void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, h
   if (ev_cell1) (void)hipEventRecord(ev_cell1, s);
 }
 
+// clears the per-column flags of the fused light pass (a kernel, not a memset node: the call may be under graph capture)
+__global__ __launch_bounds__(256) void clear_flags_kernel(int* __restrict__ flag, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = 0;
+}
+
 void launch_fused_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, const FusedDmArgs& f, const FusedParams& fp, hipStream_t s,
                                hipEvent_t ev_cell0, hipEvent_t ev_cell1, int fuse_carbonate) {
   const long long ncell = (long long)a.g.nlev * a.g.ncol;
   if (ncell <= 0) return;
+  if (f.dms && f.flag) hipLaunchKernelGGL(clear_flags_kernel, dim3((unsigned)((a.g.ncol + 255) / 256)), dim3(256), 0, s, f.flag, a.g.ncol);
   hipLaunchKernelGGL(fused_att_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, p, f.dms ? f.flag : nullptr);
   hipLaunchKernelGGL(fused_parscan_kernel, dim3((unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol)), dim3(kBlockCol), 0, s, a, p, f);
   if (ev_cell0) (void)hipEventRecord(ev_cell0, s);
