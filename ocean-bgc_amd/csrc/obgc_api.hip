@@ -125,6 +125,13 @@ bool grid_ok(const obgc_grid& g) {
 // planes, which cost nothing at that size.  Measured at 60 levels with every diagnostic (without): 2 048 columns 0.25
 // against 0.44 ms (0.18 / 0.29), 8 192 columns 0.38 against 0.46 (0.24 / 0.30), 16 384 columns 0.59 against 0.55
 // (0.35 / 0.33): the column-block kernel from 700 000 cells.  The column-block layout always takes it.
+inline bool use_column_kernel(const obgc_handle* h, const GridView& v);
+// Whether the separate kernels run their sweep as three launches (bgc_walk_kernel): native layout, batches small enough that
+// the sweep's few wavefronts are what the step waits for and the planes in between stay in the caches.
+inline bool use_split_sweep(const obgc_handle* h, const GridView& v, bool column) {
+  if (column || v.kfast || v.tiled || h->split_sweep == 0) return false;
+  return h->split_sweep >= 2 || (long long)v.nlev * v.ncol <= h->split_max_cells;
+}
 inline bool use_column_kernel(const obgc_handle* h, const GridView& v) {
   if (v.tiled) return true;
   if (h->column == 0 || v.kfast) return false;
@@ -337,6 +344,8 @@ extern "C" int obgc_create(obgc_handle** out, int device_id, unsigned flags) {
   if (const char* e = std::getenv("OBGC_KFAST_HYBRID")) h->kfast_hybrid = std::atoi(e);
   if (const char* e = std::getenv("OBGC_KFAST_DIRECT")) h->kfast_direct = std::atoi(e);
   if (const char* e = std::getenv("OBGC_SWEEP_LANES")) h->sweep_lanes = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_SPLIT_SWEEP")) h->split_sweep = std::atoi(e);
+  if (const char* e = std::getenv("OBGC_SPLIT_MAX_CELLS")) h->split_max_cells = std::atoll(e);
   if (const char* e = std::getenv("OBGC_HOST_CHUNKS")) h->host_chunks = std::atoi(e);
   if (const char* e = std::getenv("OBGC_HOST_THREADS")) h->host_threads = std::atoi(e);
   if (const char* e = std::getenv("OBGC_HOST_PIPELINE_MIN_MB")) h->host_pipeline_min_bytes = (size_t)std::atoll(e) << 20;
@@ -438,7 +447,7 @@ bool column_fuses(const obgc_handle* h, const GridView& kv, const obgc_bgc_diag*
 }
 
 size_t bgc_scratch_bytes(const obgc_handle* h, const GridView& kv, const obgc_bgc_diag* diag, bool want_zsat, bool workspace_has_all,
-                         bool column = false) {
+                         bool column = false, bool split = false) {
   const size_t kc1 = span_kc(kv, 1);
   size_t bytes = 0;
   // (the column-block kernel with the carbonate solve inside searches the saturation horizons itself)
@@ -451,6 +460,7 @@ size_t bgc_scratch_bytes(const obgc_handle* h, const GridView& kv, const obgc_bg
   const long long splane = (span1 + 31) & ~31LL;
   const int nslots = column ? 0 : (diag ? (int)S_NDIAG : (int)S_NBASE);
   bytes += align_up((size_t)nslots * splane * sizeof(double));
+  if (split) bytes += align_up((size_t)(diag ? (int)W_NDIAG : (int)W_NBASE) * splane * sizeof(double));
   if (diag) {
     const size_t zbytes = align_up((size_t)(3 * kv.plane + span1) * sizeof(double));
     const int nfb = (diag->photoC ? 0 : 1) + (diag->photoC_NO3 ? 0 : 1) + (diag->CaCO3_form ? 0 : 1) + (diag->bSi_form ? 0 : 1);
@@ -461,7 +471,7 @@ size_t bgc_scratch_bytes(const obgc_handle* h, const GridView& kv, const obgc_bg
 }
 
 // carve the scratch of one launch set out of the (already reserved) arena and hook it into K
-void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool column = false) {
+void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool column = false, bool split = false) {
   const GridView& kv = K.g;
   const size_t kc1 = span_kc(kv, 1);
   auto carve = [&](size_t bytes) -> double* {
@@ -485,6 +495,7 @@ void bgc_carve_scratch(obgc_handle* h, BgcKernelArgs& K, bool want_zsat, bool co
     K.scratch = carve((size_t)nslots * splane * sizeof(double));
     K.chl100 = K.have_diag ? K.scratch + (long long)S_CHL100 * splane : nullptr;
   }
+  K.split = split ? carve((size_t)(K.have_diag ? (int)W_NDIAG : (int)W_NBASE) * splane * sizeof(double)) : nullptr;
   K.splane = splane;
   if (K.have_diag) {
     const size_t zbytes = (size_t)(3 * kv.plane + span1) * sizeof(double);
@@ -583,7 +594,8 @@ int bgc_launch(obgc_handle* h, const BgcKernelArgs& K, bool want_zsat, const Fus
   HIP_TRY(h, hipStreamWaitEvent(h->s_aux2, h->ev_k1, 0));   // zint reads the cell kernel's profiles
   launch_bgc_zint(K, h->bgc, h->s_aux2);
   HIP_TRY(h, hipEventRecord(h->ev_aux2_done, h->s_aux2));
-  launch_bgc_ecosys_sweep(K, h->bgc, h->s_main, h->sweep_lanes);
+  if (K.split) launch_bgc_split_sweep(K, h->bgc, h->s_main);
+  else launch_bgc_ecosys_sweep(K, h->bgc, h->s_main, h->sweep_lanes);
   HIP_TRY(h, hipEventRecord(h->ev_e1, h->s_main));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux_done, 0));
   HIP_TRY(h, hipStreamWaitEvent(h->s_main, h->ev_aux2_done, 0));
@@ -906,7 +918,8 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
   obgc_bgc_diag wdiag0;                   // hybrid: the workspace owns every level-dependent plane it uses
   std::memset(&wdiag0, 0, sizeof wdiag0);
   const bool column = !tiled && use_column_kernel(h, v);   // generic strides (OBGC_KFAST_DIRECT=1) keep the separate kernels
-  size_t scratch = bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, column);
+  const bool split = !tiled && use_split_sweep(h, v, column);
+  size_t scratch = bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, column, split);
   // the tile workspace runs whichever kernel form the handle selects: reserve for the larger of the two
   if (tiled && !hybrid) scratch = std::max(scratch, bgc_scratch_bytes(h, kv, a->diag, want_zsat, tiled, h->column != 0));
   if (hybrid) {
@@ -938,7 +951,7 @@ extern "C" int obgc_bgc_source_sink(obgc_handle* h, const obgc_bgc_source_sink_a
 
   HIP_TRY(h, hipEventRecord(h->ev_begin, h->s_main));
   if (!tiled) {
-    bgc_carve_scratch(h, K, want_zsat, column);
+    bgc_carve_scratch(h, K, want_zsat, column, split);
     rc = bgc_launch(h, K, want_zsat);
     if (rc != OBGC_OK) return rc;
   } else if (hybrid) {
@@ -1073,7 +1086,8 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   // (the column-block kernel needs none of it: DMS's light runs through LDS beside BGC's)
   const bool column = use_column_kernel(h, v);
   const size_t dms_scratch = (a->dms && !column) ? 3 * align_up(kc1) + align_up((size_t)v.ncol * sizeof(int)) : 0;
-  int rc = arena_reserve(h, bgc_scratch_bytes(h, v, b.diag, want_zsat, false, column) + dms_scratch);
+  const bool split = use_split_sweep(h, v, column);
+  int rc = arena_reserve(h, bgc_scratch_bytes(h, v, b.diag, want_zsat, false, column, split) + dms_scratch);
   if (rc != OBGC_OK) return rc;
 
   BgcKernelArgs K;
@@ -1088,7 +1102,7 @@ extern "C" int obgc_fused_step(obgc_handle* h, const obgc_fused_step_args* a) {
   K.alt_co2_use_eco = b.alt_co2_use_eco;
   rc = bgc_recips(h, K);
   if (rc != OBGC_OK) return rc;
-  bgc_carve_scratch(h, K, want_zsat, column);
+  bgc_carve_scratch(h, K, want_zsat, column, split);
 
   FusedDmArgs F;
   std::memset(&F, 0, sizeof F);

@@ -1230,6 +1230,141 @@ __global__ __launch_bounds__(kBlockCol) void bgc_sweep_kernel(const BgcKernelArg
 #undef ST_C
 }
 
+// ---- the sweep of a small batch as three kernels ----
+// A few thousand columns are a few dozen sweep wavefronts, each alone on its SIMD, walking its levels through ~800 dependent
+// instructions apiece (six exp for the decay factors, the recurrence, eleven tendencies, 27 diagnostics): 2.6 us per level,
+// 60 % of the step at 2 048 columns x 60.  Only sweep_core is carried from level to level.  So: the decay factors with a lane per
+// cell (bgc_derive_kernel), the recurrence with a lane per column and nothing else in the chain (bgc_walk_kernel), the rest
+// of the level with a lane per cell again (bgc_finish_kernel), and the conservation integrals as a column sum of what that
+// left (bgc_jint_kernel).  Same functions on the same values as bgc_sweep_kernel, hence the same bits.  The planes in
+// between (SplitSlot) cost traffic a large batch would feel; small ones keep them in the caches.
+#define WPL(slot) A.split[(long long)(slot) * A.splane + ix]
+
+__global__ __launch_bounds__(256) void bgc_derive_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  const GridView& g = A.g;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.nlev * g.ncol) return;
+  const int c = (int)(idx % g.ncol), k = (int)(idx / g.ncol);
+  if (k >= A.kmax[c]) return;
+  const long long ix = g.at(k, c);
+  const double T = A.temp[ix], O2 = A.tracers[(long long)(P.ind[5] - 1) * g.plane + ix];
+  const double TfuncS = exp(div_by((T + P.T0_Kelvin_BGC) - (TREF + P.T0_Kelvin_BGC), 10.0, A.recip[R_TEN]) * LN_Q_10);
+  const LevelDerived dv = derive_level(P, A.recip, A.zbot[ix], TfuncS, dmax(0.0, O2), A.dz[ix]);
+  WPL(W_POC_DISS) = dv.poc_diss; WPL(W_SIO2_DISS) = dv.sio2_diss; WPL(W_CACO3_DISS) = dv.caco3_diss;
+  WPL(W_DECAY_POC_E) = dv.decay_POC_E; WPL(W_DECAY_SIO2) = dv.decay_SiO2; WPL(W_DECAY_CACO3) = dv.decay_CaCO3;
+  WPL(W_DECAY_DUST) = dv.decay_dust; WPL(W_DECAY_HARD) = dv.DECAY_Hard; WPL(W_DECAY_HARDDUST) = dv.DECAY_HardDust;
+}
+
+// what one level of the walk reads: nothing of it depends on the recurrence, so the next level's set is in flight while this
+// one is evaluated
+struct WalkIn {
+  double dz, zb, fesed, NO3, Fe, O2, prodPOC, prodCa, prodSi, PfeLoc;
+  LevelDerived dv;
+};
+__device__ __forceinline__ void walk_load(const BgcKernelArgs& A, const obgc_bgc_params& P, long long ix, WalkIn& L) {
+  const long long pl = A.g.plane, sp = A.splane;
+  L.dz = A.dz[ix]; L.zb = A.zbot[ix]; L.fesed = A.fesed[ix];
+  L.NO3 = A.tracers[(long long)(P.ind[1] - 1) * pl + ix]; L.Fe = A.tracers[(long long)(P.ind[4] - 1) * pl + ix];
+  L.O2 = A.tracers[(long long)(P.ind[5] - 1) * pl + ix];
+  L.prodPOC = A.scratch[(long long)S_PRODPOC * sp + ix]; L.prodCa = A.scratch[(long long)S_PRODCA * sp + ix];
+  L.prodSi = A.scratch[(long long)S_PRODSI * sp + ix]; L.PfeLoc = A.scratch[(long long)S_PFELOC * sp + ix];
+  L.dv.poc_diss = WPL(W_POC_DISS); L.dv.sio2_diss = WPL(W_SIO2_DISS); L.dv.caco3_diss = WPL(W_CACO3_DISS);
+  L.dv.decay_POC_E = WPL(W_DECAY_POC_E); L.dv.decay_SiO2 = WPL(W_DECAY_SIO2); L.dv.decay_CaCO3 = WPL(W_DECAY_CACO3);
+  L.dv.decay_dust = WPL(W_DECAY_DUST); L.dv.DECAY_Hard = WPL(W_DECAY_HARD); L.dv.DECAY_HardDust = WPL(W_DECAY_HARDDUST);
+}
+// (see settle() above: retires the first level's loads before the loop so that the loop header's wait counts are the steady state's)
+__device__ __forceinline__ void walk_settle(const WalkIn& L) {
+  asm volatile("" ::"v"(L.dz), "v"(L.zb), "v"(L.fesed), "v"(L.NO3), "v"(L.Fe), "v"(L.O2), "v"(L.prodPOC), "v"(L.prodCa), "v"(L.prodSi),
+               "v"(L.PfeLoc));
+  asm volatile("" ::"v"(L.dv.poc_diss), "v"(L.dv.sio2_diss), "v"(L.dv.caco3_diss), "v"(L.dv.decay_POC_E), "v"(L.dv.decay_SiO2),
+               "v"(L.dv.decay_CaCO3), "v"(L.dv.decay_dust), "v"(L.dv.DECAY_Hard), "v"(L.dv.DECAY_HardDust));
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockCol) void bgc_walk_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  const GridView& g = A.g;
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if (c >= g.ncol) return;
+  int kmax = A.kmax[c];
+  if (kmax > g.nlev) kmax = g.nlev;
+  SweepState S;
+  sweep_init(S, A.dust[c], kmax >= 1);
+  // one level ahead, as in bgc_sweep_kernel (a ring of three levels in flight measured slower: 63 against 52 us at 2 048 x 60)
+  WalkIn cur, nxt;
+  if (kmax >= 1) { walk_load(A, P, g.at(0, c), cur); walk_settle(cur); }
+  for (int k = 0; k < kmax; ++k) {
+    const long long ix = g.at(k, c);
+    if (k + 1 < kmax) walk_load(A, P, g.at(k + 1, c), nxt);
+    SweepCoreOut o;
+    sweep_core(P, k == kmax - 1, cur.dz, cur.zb, cur.fesed, dmax(0.0, cur.NO3), dmax(0.0, cur.Fe), dmax(0.0, cur.O2), cur.prodPOC,
+               cur.prodCa, cur.prodSi, cur.PfeLoc, cur.dv, S, o);
+    WPL(W_REMIN_POC) = o.reminPOC; WPL(W_REMIN_CA) = o.reminCa; WPL(W_REMIN_SI) = o.reminSi; WPL(W_REMIN_FE) = o.reminFe;
+    WPL(W_FE_SCAVENGE) = o.Fe_scavenge; WPL(W_SED_DENITRIF) = o.SED_DENITRIF; WPL(W_OTHER_REMIN) = o.OTHER_REMIN;
+    if (DIAG) {
+      WPL(W_IN_POC) = o.inPOC; WPL(W_IN_CA) = o.inCa; WPL(W_IN_SI) = o.inSi; WPL(W_IN_DUST) = o.inDust; WPL(W_IN_FE) = o.inFe;
+      WPL(W_REMIN_DUST) = o.reminDust; WPL(W_FE_SCAV_RATE) = o.Fe_scav_rate;
+      WPL(W_SED_POC) = o.sedPOC; WPL(W_SED_CA) = o.sedCa; WPL(W_SED_SI) = o.sedSi; WPL(W_SED_DUST) = o.sedDust; WPL(W_SED_FE) = o.sedFe;
+    }
+    cur = nxt;
+  }
+}
+
+// the rest of the level (sweep_finish) for every active cell; with diagnostics the integrands of the conservation integrals
+// replace their local parts in the hand-off planes (same cell, read before written)
+template <bool DIAG>
+__global__ __launch_bounds__(256) void bgc_finish_kernel(const BgcKernelArgs A, const obgc_bgc_params P) {
+  const GridView& g = A.g;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.nlev * g.ncol) return;
+  const int c = (int)(idx % g.ncol), k = (int)(idx / g.ncol);
+  if (k >= A.kmax[c]) return;
+  const long long ix = g.at(k, c);
+  LevelIn<DIAG> cur;
+  load_level<DIAG>(A, P, ix, cur);
+  SweepCoreOut o;
+  o.reminPOC = WPL(W_REMIN_POC); o.reminCa = WPL(W_REMIN_CA); o.reminSi = WPL(W_REMIN_SI); o.reminFe = WPL(W_REMIN_FE);
+  o.Fe_scavenge = WPL(W_FE_SCAVENGE); o.SED_DENITRIF = WPL(W_SED_DENITRIF); o.OTHER_REMIN = WPL(W_OTHER_REMIN);
+  if (DIAG) {
+    o.inPOC = WPL(W_IN_POC); o.inCa = WPL(W_IN_CA); o.inSi = WPL(W_IN_SI); o.inDust = WPL(W_IN_DUST); o.inFe = WPL(W_IN_FE);
+    o.reminDust = WPL(W_REMIN_DUST); o.Fe_scav_rate = WPL(W_FE_SCAV_RATE);
+    o.sedPOC = WPL(W_SED_POC); o.sedCa = WPL(W_SED_CA); o.sedSi = WPL(W_SED_SI); o.sedDust = WPL(W_SED_DUST); o.sedFe = WPL(W_SED_FE);
+  }
+  const JTerms jt = sweep_finish<DIAG>(A, P, ix, cur, o);
+  if (DIAG) {
+    const long long sp = A.splane;
+    A.scratch[(long long)S_JC * sp + ix] = jt.C; A.scratch[(long long)S_JN * sp + ix] = jt.N;
+    A.scratch[(long long)S_JP * sp + ix] = jt.P; A.scratch[(long long)S_JSI * sp + ix] = jt.Si;
+  }
+}
+
+// conservation integrals of the columns from the integrands bgc_finish_kernel left, top to bottom (accumulate_J)
+__global__ __launch_bounds__(kBlockCol) void bgc_jint_kernel(const BgcKernelArgs A) {
+  const GridView& g = A.g;
+  const int c = blockIdx.x * kBlockCol + threadIdx.x;
+  if (c >= g.ncol) return;
+  const obgc_bgc_diag& D = A.diag;
+  int kmax = A.kmax[c];
+  if (kmax > g.nlev) kmax = g.nlev;
+  const long long sp = A.splane;
+  double J[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double zbot_above = 0.0;
+  // (eight levels of loads fetched ahead of their sums measured slower than this: 47 against 29 us at 2 048 x 60)
+#pragma unroll 4
+  for (int k = 0; k < kmax; ++k) {
+    const long long ix = g.at(k, c);
+    const JTerms jt{A.scratch[(long long)S_JC * sp + ix], A.scratch[(long long)S_JN * sp + ix], A.scratch[(long long)S_JP * sp + ix],
+                    A.scratch[(long long)S_JSI * sp + ix]};
+    const double zb = A.zbot[ix];
+    accumulate_J(J, jt, A.dz[ix], zb, zbot_above, WPL(W_SED_POC), WPL(W_SED_CA), WPL(W_SED_SI));
+    zbot_above = zb;
+  }
+#define ST_C(name, v) do { if (D.name) D.name[c] = (v); } while (0)
+  ST_C(Jint_Ctot, J[0]); ST_C(Jint_100m_Ctot, J[1]); ST_C(Jint_Ntot, J[2]); ST_C(Jint_100m_Ntot, J[3]);
+  ST_C(Jint_Ptot, J[4]); ST_C(Jint_100m_Ptot, J[5]); ST_C(Jint_Sitot, J[6]); ST_C(Jint_100m_Sitot, J[7]);
+#undef ST_C
+}
+#undef WPL
+
 // the recurrence state of a column (five fluxes, the dust deficit) to / from its LDS row
 constexpr int kStateVals = 11;
 __device__ __forceinline__ void state_store(const SweepState& S, double (*st)[64], int lane) {
@@ -1553,7 +1688,8 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
   double o2min = 0.0, o2min_z = 0.0;
   const double* chl100 = A.chl100;
   const double* o2p = A.tracers + (long long)(P.ind[5] - 1) * pl;
-  // not unrolled: three wavefronts per SIMD instead of two (2.68 against 2.80 ms at 1 M x 80)
+  // not unrolled: three wavefronts per SIMD instead of two (2.68 against 2.80 ms at 1 M x 80); small batches, whose few
+  // wavefronts are alone on their SIMDs, gain nothing from four levels at a time either (103 against 93 us at 2 048 x 60)
 #pragma unroll 1
   for (int k = 0; k < kmax; ++k) {
     const long long ix = g.at(k, c);
@@ -1773,6 +1909,20 @@ static void launch_sweep_lanes(const BgcKernelArgs& a, const obgc_bgc_params& p,
   const unsigned grid = (unsigned)((a.g.ncol + LANES - 1) / LANES);
   if (a.have_diag) hipLaunchKernelGGL((bgc_sweep_kernel<true, LANES>), dim3(grid), dim3(kBlockCol), 0, s, a, p);
   else hipLaunchKernelGGL((bgc_sweep_kernel<false, LANES>), dim3(grid), dim3(kBlockCol), 0, s, a, p);
+}
+
+void launch_bgc_split_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s) {
+  if (a.g.ncol <= 0) return;
+  const unsigned gcell = (unsigned)(((long long)a.g.nlev * a.g.ncol + 255) / 256), gcol = (unsigned)((a.g.ncol + kBlockCol - 1) / kBlockCol);
+  hipLaunchKernelGGL(bgc_derive_kernel, dim3(gcell), dim3(256), 0, s, a, p);
+  if (a.have_diag) {
+    hipLaunchKernelGGL(bgc_walk_kernel<true>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+    hipLaunchKernelGGL(bgc_finish_kernel<true>, dim3(gcell), dim3(256), 0, s, a, p);
+    hipLaunchKernelGGL(bgc_jint_kernel, dim3(gcol), dim3(kBlockCol), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(bgc_walk_kernel<false>, dim3(gcol), dim3(kBlockCol), 0, s, a, p);
+    hipLaunchKernelGGL(bgc_finish_kernel<false>, dim3(gcell), dim3(256), 0, s, a, p);
+  }
 }
 
 void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int lanes) {

@@ -19,6 +19,10 @@ struct obgc_handle {
              ev_t0 = nullptr, ev_t1 = nullptr, ev_aux_done = nullptr, ev_aux2_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool timed_valid = false, tr_valid = false, cell_valid = false;
   int last_sched = -1;    // schedule the last obgc_bgc_source_sink / obgc_fused_step used (obgc_last_schedule)
+  // the separate kernels' sweep as three launches (bgc_walk_kernel): 0 never, 1 for batches up to split_max_cells, 2 always
+  // (OBGC_SPLIT_SWEEP, OBGC_SPLIT_MAX_CELLS)
+  int split_sweep = 1;
+  long long split_max_cells = 300000;
   int sweep_lanes = 0;    // experiment knob OBGC_SWEEP_LANES: 16 / 32 / 64 active lanes per wavefront in the sweep, 0 = auto
   int kfast_tile = 131072;   // columns per transposed tile of the reference-layout path (OBGC_KFAST_TILE)
   int kfast_direct = 0;   // experiment knob OBGC_KFAST_DIRECT=1: run the kernels on the reference layout through strides

@@ -66,6 +66,17 @@ enum ScratchSlot {
   S_NDIAG
 };
 
+// Planes of the particle sweep when it runs as three kernels (small batches, bgc_walk_kernel): the level's dissolution
+// lengths and decay factors in front of the recurrence, what one step of the recurrence leaves behind it.
+enum SplitSlot {
+  W_POC_DISS, W_SIO2_DISS, W_CACO3_DISS, W_DECAY_POC_E, W_DECAY_SIO2, W_DECAY_CACO3, W_DECAY_DUST, W_DECAY_HARD, W_DECAY_HARDDUST,
+  W_REMIN_POC, W_REMIN_CA, W_REMIN_SI, W_REMIN_FE, W_FE_SCAVENGE, W_SED_DENITRIF, W_OTHER_REMIN,
+  W_NBASE,
+  W_IN_POC = W_NBASE, W_IN_CA, W_IN_SI, W_IN_DUST, W_IN_FE, W_REMIN_DUST, W_FE_SCAV_RATE,   // diagnostics only
+  W_SED_POC, W_SED_CA, W_SED_SI, W_SED_DUST, W_SED_FE,
+  W_NDIAG
+};
+
 // ---------------------------------------------------------------- kernel arguments
 struct BgcKernelArgs {
   GridView g;
@@ -84,6 +95,8 @@ struct BgcKernelArgs {
   long long splane;
   // separate kernels with diagnostics: chlorophyll x thickness above 100 m of every cell, summed by the column-integral kernel
   double* chl100;
+  // small batches: the sweep as three kernels, SplitSlot planes (NULL = the one-kernel sweep)
+  double* split;
   // the column-block kernel advances the conservation integrals, the O2 minimum and the 100 m chlorophyll integral itself
   // (and the saturation horizons when it solves the carbonate system): the column-integral kernel skips them
   int colint;
@@ -186,6 +199,8 @@ void launch_bgc_zsat(const BgcKernelArgs& a, hipStream_t s);
 void launch_bgc_ecosys_cells(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, hipEvent_t ev_cell0, hipEvent_t ev_cell1,
                              int fuse_carbonate);
 void launch_bgc_ecosys_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s, int lanes);
+// the same results from three launches (a.split != NULL): decay factors per cell, the recurrence per column, the rest per cell
+void launch_bgc_split_sweep(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_zint(const BgcKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_bgc_surface(const SurfKernelArgs& a, const obgc_bgc_params& p, hipStream_t s);
 void launch_dms(const DmsKernelArgs& a, const obgc_dms_params& p, hipStream_t s);   // att -> PAR scan -> cell kernel

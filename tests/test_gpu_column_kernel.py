@@ -204,3 +204,48 @@ def test_small_batches_take_the_separate_kernels_by_default(pkg, synth, monkeypa
         fb = forced.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0)
         for part in ("bgc", "dms", "macros"):
             _same(fa[part], fb[part], "fused %s %d" % (part, nc))
+
+
+@pytest.mark.parametrize("diagnostics", [True, False])
+def test_small_batch_sweep_in_three_launches_same_bits(pkg, synth, monkeypatch, diagnostics):
+    """Small native-layout batches run the particle sweep as decay factors per cell, the recurrence per column and the rest
+    of the level per cell (bgc_walk_kernel): the bits of the one-kernel sweep and of the column-block kernel, for
+    BGC_SourceSink and the fused step, cold and warm, on a ragged column count with empty columns in it."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    from ocean_bgc_amd.modules import ColumnEngine
+    monkeypatch.setenv("OBGC_COLUMN_KERNEL", "0")
+    monkeypatch.setenv("OBGC_SPLIT_SWEEP", "0")
+    whole = ColumnEngine(0, path="device_colfast")
+    monkeypatch.setenv("OBGC_SPLIT_SWEEP", "2")
+    split = ColumnEngine(0, path="device_colfast")
+    monkeypatch.setenv("OBGC_COLUMN_KERNEL", "2")
+    column = ColumnEngine(0, path="device_colfast")
+    for nc, nz in ((777, 60), (5_001, 80)):
+        syn = synth.generate(nc, nz, col0=31_000)
+        syn["kmax"][5::97] = 0                       # land columns
+        syn["kmax"][11::89] = 1                      # one active level: the surface is the sea floor
+        tr, dtr, mtr = synth.bgc_tracer_array(syn), synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)
+        args = (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"],
+                syn["sw"])
+        z = np.zeros((nc, nz))
+        a = whole.BGC_SourceSink(*args, z, z, diag_init=-5.0, diagnostics=diagnostics)
+        b = split.BGC_SourceSink(*args, z, z, diag_init=-5.0, diagnostics=diagnostics)
+        c = column.BGC_SourceSink(*args, z, z, diag_init=-5.0, diagnostics=diagnostics)
+        assert whole.eng.last_schedule() in (0, 1, 2) and split.eng.last_schedule() in (0, 1, 2) and column.eng.last_schedule() in (3, 4)
+        _same(a, b, "bgc %d" % nc)
+        _same(c, b, "bgc %d against the column-block kernel" % nc)
+        assert np.isfinite(b["tend"]).all() and np.abs(b["tend"]).max() > 0
+        # warm second step on moved tracers
+        a2 = whole.BGC_SourceSink(tr * 1.003, *args[1:], a["ph_prev"], a["ph_prev_alt"], diag_init=-5.0, diagnostics=diagnostics)
+        b2 = split.BGC_SourceSink(tr * 1.003, *args[1:], b["ph_prev"], b["ph_prev_alt"], diag_init=-5.0, diagnostics=diagnostics)
+        _same(a2, b2, "bgc warm %d" % nc)
+        sst = syn["forcing"]["SST"]
+        fa = whole.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0, diagnostics=diagnostics)
+        fb = split.Fused_SourceSink(*args, z, z, sst, dtr, mtr, diag_init=-5.0, diagnostics=diagnostics)
+        for part in ("bgc", "dms", "macros"):
+            if diagnostics:
+                _same(fa[part], fb[part], "fused %s %d" % (part, nc))
+            else:
+                assert np.array_equal(fa[part]["tend"], fb[part]["tend"]), (part, nc)
+        _same(fb["bgc"], b, "fused bgc against the BGC call %d" % nc)
