@@ -1688,24 +1688,38 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
   double o2min = 0.0, o2min_z = 0.0;
   const double* chl100 = A.chl100;
   const double* o2p = A.tracers + (long long)(P.ind[5] - 1) * pl;
-  // not unrolled: three wavefronts per SIMD instead of two (2.68 against 2.80 ms at 1 M x 80); small batches, whose few
-  // wavefronts are alone on their SIMDs, gain nothing from four levels at a time either (103 against 93 us at 2 048 x 60)
+  bool has_si[4], calcifies[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { has_si[a] = at[a].Si_ind > 0; calcifies[a] = at[a].imp_calcifier != 0; }
+  // not unrolled: three wavefronts per SIMD instead of two (2.68 against 2.80 ms at 1 M x 80); four levels at a time gain a
+  // small batch nothing either
 #pragma unroll 1
   for (int k = 0; k < kmax; ++k) {
     const long long ix = g.at(k, c);
+    // every load of the level first, the sums behind them: one memory round trip per level.  With each load next to its sum
+    // the wavefront waited once per autotroph and conditional -- up to a dozen round trips a level, which is all a batch of a
+    // few hundred wavefronts spends its time on.
     const double dz = A.dz[ix];
-    if (!COLINT) {
-      const double O2 = dmax(0.0, o2p[ix]);
-      if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = A.zmid[ix]; }
-    }
-    double pC[4];
+    double O2raw = 0.0, zm = 0.0, chl = 0.0;
+    if (!COLINT) { O2raw = o2p[ix]; zm = A.zmid[ix]; chl = chl100[ix]; }
+    double pC[4], pN[4], bSi[4], Ca[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       pC[a] = A.z_photoC[(long long)a * pl + ix];
+      pN[a] = A.z_photoC_NO3[(long long)a * pl + ix];
+      bSi[a] = has_si[a] ? A.z_bSi_form[(long long)a * pl + ix] : 0.0;
+      Ca[a] = calcifies[a] ? A.z_CaCO3_form[(long long)a * pl + ix] : 0.0;
+    }
+    if (!COLINT) {
+      const double O2 = dmax(0.0, O2raw);
+      if (k == 0 || O2 < o2min) { o2min = O2; o2min_z = zm; }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
       z_pC[a] = z_pC[a] + dz * pC[a];
-      if (at[a].Si_ind > 0) z_bSi = z_bSi + A.z_bSi_form[(long long)a * pl + ix];
-      if (at[a].imp_calcifier) {
-        const double w = dz * A.z_CaCO3_form[(long long)a * pl + ix];
+      if (has_si[a]) z_bSi = z_bSi + bSi[a];
+      if (calcifies[a]) {
+        const double w = dz * Ca[a];
         z_Ca[a] = z_Ca[a] + w;
         z_CaTot = z_CaTot + w;
       }
@@ -1713,10 +1727,10 @@ __global__ __launch_bounds__(kBlockCol) void bgc_zint_kernel(const BgcKernelArgs
     z_pCTot = z_pCTot + sum4(pC) * dz;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      z_pCNO3[a] = z_pCNO3[a] + A.z_photoC_NO3[(long long)a * pl + ix] * dz;
+      z_pCNO3[a] = z_pCNO3[a] + pN[a] * dz;
       z_pCNO3Tot = z_pCNO3Tot + z_pCNO3[a];   // adds the RUNNING integral (1844-1846)
     }
-    if (!COLINT) z_Chl100 = z_Chl100 + chl100[ix];
+    if (!COLINT) z_Chl100 = z_Chl100 + chl;
   }
   if (!COLINT) {
     if (D.O2_ZMIN) D.O2_ZMIN[c] = o2min;
