@@ -6,6 +6,7 @@
 //   layout 0  plane-major (the native layout):       X[plane][level][column]
 //   layout 1  level-major tiles:                     X[level][block][plane][64]      block = 64 adjacent columns
 //   layout 2  column-block-major tiles:              X[block][level][plane][64]      a workgroup's whole output is one run
+//   probe_pairs: layout 2 with two planes interleaved per column, X[block][level][plane / 2][64][2]: 16-byte accesses
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/bw_probe3.hip -o gpurun_out/bw_probe3 && gpurun_out/bw_probe3 [ncol] [nlev]
 #include <hip/hip_runtime.h>
@@ -38,6 +39,40 @@ __global__ __launch_bounds__(256, 2) void probe(const double* __restrict__ in, d
       out[addr<LOUT>(p, k, b, lane, NOUT, nlev, nblk)] = v;
     }
   }
+}
+
+// two planes per access: a lane reads / writes the values of planes 2q and 2q + 1 of its column as one 16-byte access
+template <int NIN, int NOUT>
+__global__ __launch_bounds__(256, 2) void probe_pairs(const double2* __restrict__ in, double2* __restrict__ out, int nlev, long long nblk) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long b = blockIdx.x;
+  for (int k = w; k < nlev; k += 4) {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NIN / 2; ++q) { const double2 v = in[((b * nlev + k) * (NIN / 2) + q) * 64 + lane]; acc += v.x + v.y; }
+    if (acc == 12345.678) lds[threadIdx.x] = acc;
+#pragma unroll
+    for (int q = 0; q < NOUT / 2; ++q) out[((b * nlev + k) * (NOUT / 2) + q) * 64 + lane] = make_double2(acc + 2 * q, acc + 2 * q + 1);
+  }
+}
+
+template <int NIN, int NOUT>
+void run_pairs(const double* in, double* out, int ncol, int nlev) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const long long nblk = ncol / 64;
+  const size_t shm = 70 * 1024;
+  CK(hipFuncSetAttribute((const void*)probe_pairs<NIN, NOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int r = 0; r < 2; ++r) probe_pairs<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>((const double2*)in, (double2*)out, nlev, nblk);
+  CK(hipEventRecord(a));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) probe_pairs<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>((const double2*)in, (double2*)out, nlev, nblk);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+  const double bytes = 8.0 * nblk * 64 * nlev * (NIN + NOUT);
+  printf("in %3d out %3d, column blocks, two planes per 16-byte access : %8.3f ms  %6.2f TB/s\n", NIN, NOUT, ms, bytes / ms * 1e-9);
+  fflush(stdout);
 }
 
 template <int NIN, int NOUT, int LIN, int LOUT, int WORK>
@@ -74,6 +109,8 @@ int main(int argc, char** argv) {
   run<43, 200, 0, 0, 4>(in, out, ncol, nlev);
   run<43, 200, 0, 2, 4>(in, out, ncol, nlev);
   run<43, 200, 2, 2, 4>(in, out, ncol, nlev);
+  run_pairs<44, 200>(in, out, ncol, nlev);
+  run_pairs<0, 200>(in, out, ncol, nlev);
   run<43, 37, 0, 0, 0>(in, out, ncol, nlev);    // tendencies only
   run<43, 37, 2, 2, 0>(in, out, ncol, nlev);
   run<0, 200, 0, 0, 0>(in, out, ncol, nlev);    // writes only
