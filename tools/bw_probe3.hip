@@ -8,11 +8,13 @@
 //   layout 2  column-block-major tiles:              X[block][level][plane][64]      a workgroup's whole output is one run
 //   probe_pairs: layout 2 with two planes interleaved per column, X[block][level][plane / 2][64][2]: 16-byte accesses
 //
-//   hipcc --offload-arch=gfx950 -O3 tools/bw_probe3.hip -o gpurun_out/bw_probe3 && gpurun_out/bw_probe3 [ncol] [nlev]
+//   hipcc --offload-arch=gfx950 -O3 tools/bw_probe3.hip -o gpurun_out/bw_probe3 && gpurun_out/bw_probe3 [ncol] [nlev] [LDS KB per workgroup]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static size_t g_shm_kb = 70;   // LDS per workgroup: 70 KB = two workgroups per CU (the column kernel's occupancy), 140 KB = one
 
 template <int LAYOUT>
 __device__ __forceinline__ long long addr(int p, int k, int b, int lane, int np, int nlev, long long nblk) {
@@ -62,7 +64,7 @@ void run_pairs(const double* in, double* out, int ncol, int nlev) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const long long nblk = ncol / 64;
-  const size_t shm = 70 * 1024;
+  const size_t shm = g_shm_kb * 1024;
   CK(hipFuncSetAttribute((const void*)probe_pairs<NIN, NOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   for (int r = 0; r < 2; ++r) probe_pairs<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>((const double2*)in, (double2*)out, nlev, nblk);
   CK(hipEventRecord(a));
@@ -80,7 +82,7 @@ void run(const double* in, double* out, int ncol, int nlev) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const long long nblk = ncol / 64;
-  const size_t shm = 70 * 1024;
+  const size_t shm = g_shm_kb * 1024;
   CK(hipFuncSetAttribute((const void*)probe<NIN, NOUT, LIN, LOUT, WORK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   for (int r = 0; r < 2; ++r) probe<NIN, NOUT, LIN, LOUT, WORK><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
   CK(hipEventRecord(a));
@@ -96,11 +98,12 @@ void run(const double* in, double* out, int ncol, int nlev) {
 int main(int argc, char** argv) {
   const int ncol = (argc > 1) ? atoi(argv[1]) : 320000;   // a multiple of 64
   const int nlev = (argc > 2) ? atoi(argv[2]) : 80;
+  if (argc > 3) g_shm_kb = (size_t)atoi(argv[3]);
   const long long n = (long long)ncol * nlev;
   double *in, *out;
   CK(hipMalloc(&in, 8 * n * 48)); CK(hipMalloc(&out, 8 * n * 200));
   CK(hipMemset(in, 0, 8 * n * 48)); CK(hipMemset(out, 0, 8 * n * 200));
-  printf("%d columns x %d levels, %.1f GB\n", ncol, nlev, 8.0 * n * 248 * 1e-9);
+  printf("%d columns x %d levels, %.1f GB, %zu KB of LDS per workgroup\n", ncol, nlev, 8.0 * n * 248 * 1e-9, g_shm_kb);
   run<43, 200, 0, 0, 0>(in, out, ncol, nlev);
   run<43, 200, 0, 1, 0>(in, out, ncol, nlev);
   run<43, 200, 0, 2, 0>(in, out, ncol, nlev);
