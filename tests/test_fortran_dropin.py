@@ -34,19 +34,12 @@ def test_shim_sources_are_in_sync_with_the_header():
         assert name in src
 
 
-@pytest.mark.gpu
-def test_fortran_host_matches_oracle(tmp_path, synth, oracle):
-    if not has_gpu():
-        pytest.fail("needs a GPU")
-    if not os.path.exists(EXE):
-        subprocess.check_call(["make", "-s", "-C", FDIR])
-    nc, nz = 1500, 60
-    syn = synth.generate(nc, nz, col0=4242)
+def _write_inputs(synth, path, nc, nz, col0):
+    syn = synth.generate(nc, nz, col0=col0)
     tr = synth.bgc_tracer_array(syn)
     dtr, mtr = synth.dms_tracer_array(syn), synth.macros_tracer_array(syn)
     f = syn["forcing"]
-    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(fin, "wb") as fh:
+    with open(path, "wb") as fh:
         np.array([nz, nc], dtype=np.int32).tofile(fh)
         for a in (tr, syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"]):
             np.ascontiguousarray(a, dtype=np.float64).tofile(fh)
@@ -55,6 +48,18 @@ def test_fortran_host_matches_oracle(tmp_path, synth, oracle):
                   f["atmCO2"], f["atmCO2_ALT_CO2"], f["surface_pH"], f["surface_pH_alt_co2"], f["surfaceDepth"], f["SST"],
                   f["SSS"], syn["depositionFlux"], syn["riverFlux"], syn["gasFlux"], syn["seaIceFlux"], dtr, mtr):
             np.ascontiguousarray(a, dtype=np.float64).tofile(fh)
+    return syn, tr, dtr, mtr, f
+
+
+@pytest.mark.gpu
+def test_fortran_host_matches_oracle(tmp_path, synth, oracle):
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    nc, nz = 1500, 60
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    syn, tr, dtr, mtr, f = _write_inputs(synth, fin, nc, nz, 4242)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     res = subprocess.run([EXE, fin, fout], env=env, capture_output=True, text=True, timeout=300)
@@ -102,3 +107,44 @@ def test_fortran_host_matches_oracle(tmp_path, synth, oracle):
     rep.note("diag", "DMS_R_TOTAL", P.e_norm(dr[active], d["kc"]["DMS_R_TOTAL"][active]), P.TOL_DIAG)
     rep.note("diag", "LIP_R_TOTAL", P.e_norm(lr[active], m["kc"]["LIP_R_TOTAL"][active]), P.TOL_DIAG)
     assert rep.ok(), "\n".join(rep.fail[:10])
+
+
+@pytest.mark.gpu
+def test_fortran_host_selects_diagnostics_by_name(tmp_path, synth):
+    """obgc_bgc_select_diagnostics (an extension of the drop-in BGC_mod): the members the host names are the bits of the run
+    that fills every member, every other member keeps what the host had in it, tendencies and pH do not change; an unknown
+    name stops the program with a message that names it."""
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    nc, nz = 900, 60
+    fin = str(tmp_path / "in.bin")
+    _write_inputs(synth, fin, nc, nz, 777)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+
+    def run(*sel):
+        fout = str(tmp_path / ("out%d.bin" % len(sel)))
+        res = subprocess.run([EXE, fin, fout, *sel], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout + res.stderr
+        raw = np.fromfile(fout, dtype=np.float64)
+        pos, out = 0, {}
+        for nm, shape in (("tend", (30, nc, nz)), ("php", (nc, nz)), ("pha", (nc, nz)), ("CO3", (nc, nz)), ("POC_FLUX_IN", (nc, nz)),
+                          ("photoC", (4, nc, nz)), ("POC_ACCUM", (nc, nz)), ("zsatcalc", (nc,)), ("Jint_Ctot", (nc,))):
+            n = int(np.prod(shape))
+            out[nm] = raw[pos:pos + n].reshape(shape)
+            pos += n
+        return out
+
+    full = run()
+    part = run("photoC, zsatcalc Jint_Ctot")             # commas and blanks both separate names
+    for nm in ("tend", "php", "pha", "photoC", "zsatcalc", "Jint_Ctot"):
+        assert np.array_equal(full[nm], part[nm]), nm
+    assert (full["CO3"] != -7.0).any() and (full["POC_FLUX_IN"] != -7.0).any()
+    for nm in ("CO3", "POC_FLUX_IN", "POC_ACCUM"):      # not selected: what the host had there
+        assert (part[nm] == -7.0).all(), nm
+    none = run("none")
+    assert np.array_equal(full["tend"], none["tend"]) and (none["photoC"] == -7.0).all() and (none["zsatcalc"] == -7.0).all()
+    res = subprocess.run([EXE, fin, str(tmp_path / "bad.bin"), "photoC no_such_member"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "no member diag_no_such_member" in res.stdout + res.stderr

@@ -16,7 +16,11 @@ for nm in L.BGC_DIAG_KCA: diag[nm] = np.zeros((4, nc, nz))
 for nm in L.BGC_DIAG_CA: diag[nm] = np.zeros((4, nc))
 for nm in L.BGC_DIAG_C: diag[nm] = np.zeros((nc,))
 cells = int(syn["kmax"].sum())
-for dg, name in ((diag, "full"), (None, "none")):
+# a host that reads a handful of members (what obgc_bgc_select_diagnostics of the Fortran drop-in passes on): six planes and
+# the column integrals instead of 133 planes
+few = {nm: diag[nm] for nm in ("CO3", "pH_3D", "O2_CONSUMPTION", "POC_FLUX_IN", "photoC_TOT", "NITRIF", "photoC_TOT_zint",
+                               "Jint_Ctot", "zsatcalc", "O2_ZMIN")}
+for dg, name in ((diag, "full"), (few, "ten selected members"), (None, "none")):
     ts = []
     for i in range(4):
         ph[:] = 0; t0 = time.perf_counter()
