@@ -131,10 +131,13 @@ def test_fortran_host_selects_diagnostics_by_name(tmp_path, synth):
         raw = np.fromfile(fout, dtype=np.float64)
         pos, out = 0, {}
         for nm, shape in (("tend", (30, nc, nz)), ("php", (nc, nz)), ("pha", (nc, nz)), ("CO3", (nc, nz)), ("POC_FLUX_IN", (nc, nz)),
-                          ("photoC", (4, nc, nz)), ("POC_ACCUM", (nc, nz)), ("zsatcalc", (nc,)), ("Jint_Ctot", (nc,))):
+                          ("photoC", (4, nc, nz)), ("POC_ACCUM", (nc, nz)), ("zsatcalc", (nc,)), ("Jint_Ctot", (nc,)),
+                          ("netFlux", (30, nc)), ("sph", (nc,)), ("ice", (nc,)), ("pco2", (nc,)), ("dms_tend", (14, nc, nz)),
+                          ("DMS_R_TOTAL", (nc, nz)), ("macros_tend", (8, nc, nz)), ("LIP_R_TOTAL", (nc, nz))):
             n = int(np.prod(shape))
             out[nm] = raw[pos:pos + n].reshape(shape)
             pos += n
+        assert pos == raw.size
         return out
 
     full = run()
@@ -146,5 +149,13 @@ def test_fortran_host_selects_diagnostics_by_name(tmp_path, synth):
         assert (part[nm] == -7.0).all(), nm
     none = run("none")
     assert np.array_equal(full["tend"], none["tend"]) and (none["photoC"] == -7.0).all() and (none["zsatcalc"] == -7.0).all()
+    # the same for DMS_diagnostics_type and MACROS_diagnostics_type (obgc_dms_select_diagnostics, obgc_macros_select_diagnostics)
+    assert (full["DMS_R_TOTAL"] != -7.0).any() and (full["LIP_R_TOTAL"] != -7.0).any()
+    own = run("all", "DMS_S_TOTAL", "none")
+    assert (own["DMS_R_TOTAL"] == -7.0).all() and (own["LIP_R_TOTAL"] == -7.0).all()
+    assert np.array_equal(own["dms_tend"], full["dms_tend"]) and np.array_equal(own["macros_tend"], full["macros_tend"])
+    assert np.array_equal(own["CO3"], full["CO3"])
+    own = run("all", "DMS_R_TOTAL DMS_S_TOTAL", "LIP_R_TOTAL")
+    assert np.array_equal(own["DMS_R_TOTAL"], full["DMS_R_TOTAL"]) and np.array_equal(own["LIP_R_TOTAL"], full["LIP_R_TOTAL"])
     res = subprocess.run([EXE, fin, str(tmp_path / "bad.bin"), "photoC no_such_member"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "no member diag_no_such_member" in res.stdout + res.stderr
