@@ -420,6 +420,14 @@ typedef struct {
  * inside the block); with dmsTracers / macrosTracers also DMS_SurfaceFluxes and the fused BGC + DMS + MACROS step */
 int obgc_block_step(obgc_block *b, const obgc_block_step_args *a);
 
+/* Diagnostics of the block's steps.  The block keeps its state in the native layout, so diagnostics are computed into
+ * DEVICE arrays of that index space: COLFAST, nlev = nVertLevels, ncol = ld = ldc = nCells -- what an obgc_diag_set created
+ * for such a grid owns (pass obgc_diag_set_bgc / _dms / _macros of the set; the host then accumulates, downloads or writes
+ * through the set, in the reference's (k,column) order = the model's (nVertLevels, nCells)).  Every later step of the
+ * block fills the non-NULL members; a NULL struct = none of that module (the default).  The structs are copied, the arrays
+ * they point to must outlive the steps.  DMS / MACROS members are filled by steps that are given dmsTracers / macrosTracers. */
+int obgc_block_set_diagnostics(obgc_block *b, const obgc_bgc_diag *bgc, const obgc_dms_diag *dms, const obgc_macros_diag *macros);
+
 /* The same step for a model whose arrays already live on the handle's GPU (an OpenACC / OpenMP-offloaded or HIP ocean
  * model): every pointer of obgc_block_step_args is a DEVICE pointer, in the same tracer-fastest layout and units.  The
  * layout change reads the model's arrays and writes (or adds to) its tendency and flux arrays directly: nothing is staged,

@@ -33,6 +33,11 @@ struct obgc_block {
   char* pool2 = nullptr;
   double *own = nullptr, *own_tend = nullptr, *dms_surf_tr = nullptr, *dms_net = nullptr;
   double *m_own[2] = {nullptr, nullptr}, *m_own_tend[2] = {nullptr, nullptr}, *m_dms_sflux = nullptr;
+  // diagnostics the steps fill (obgc_block_set_diagnostics): device pointer structs in the block's index space
+  obgc_bgc_diag bgc_diag;
+  obgc_dms_diag dms_diag;
+  obgc_macros_diag macros_diag;
+  bool have_bgc_diag = false, have_dms_diag = false, have_macros_diag = false;
 };
 
 namespace obgc {
@@ -172,6 +177,9 @@ extern "C" int obgc_block_create(obgc_handle* h, int nCells, int nVertLevels, ob
   b->h = h;
   b->nc = nCells;
   b->nz = nVertLevels;
+  std::memset(&b->bgc_diag, 0, sizeof b->bgc_diag);
+  std::memset(&b->dms_diag, 0, sizeof b->dms_diag);
+  std::memset(&b->macros_diag, 0, sizeof b->macros_diag);
   const size_t nc = (size_t)nCells, kc = nc * (size_t)nVertLevels, al = 256;
   size_t total = 0;
   auto plan = [&](size_t bytes) { size_t o = total; total += (bytes + al - 1) / al * al; return o; };
@@ -215,6 +223,20 @@ extern "C" int obgc_block_destroy(obgc_block* b) {
   if (b->pool_m) (void)hipFree(b->pool_m);
   if (b->pool2) (void)hipFree(b->pool2);
   delete b;
+  return OBGC_OK;
+}
+
+extern "C" int obgc_block_set_diagnostics(obgc_block* b, const obgc_bgc_diag* bgc, const obgc_dms_diag* dms, const obgc_macros_diag* macros) {
+  if (!b) return OBGC_ERR_INVALID;
+  std::memset(&b->bgc_diag, 0, sizeof b->bgc_diag);
+  std::memset(&b->dms_diag, 0, sizeof b->dms_diag);
+  std::memset(&b->macros_diag, 0, sizeof b->macros_diag);
+  if (bgc) b->bgc_diag = *bgc;
+  if (dms) b->dms_diag = *dms;
+  if (macros) b->macros_diag = *macros;
+  b->have_bgc_diag = bgc != nullptr;
+  b->have_dms_diag = dms != nullptr;
+  b->have_macros_diag = macros != nullptr;
   return OBGC_OK;
 }
 
@@ -343,12 +365,26 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
   sf.lcalc_O2_gas_flux = 1; sf.lcalc_CO2_gas_flux = 1;
   int rc = obgc_bgc_surface_fluxes(b->h, &sf);
   if (rc != OBGC_OK) return rc;
+  // the diagnostics of the block, seen from this cell range: every member is indexed (level, cell[, autotroph]) or
+  // (cell[, autotroph]) with the block's strides, so the range starts c0 elements further in each of them
+  obgc_bgc_diag dg_bgc = b->bgc_diag;
+  obgc_dms_diag dg_dms = b->dms_diag;
+  obgc_macros_diag dg_macros = b->macros_diag;
+#define X(n) if (dg_bgc.n) dg_bgc.n += c0;
+  OBGC_BGC_DIAG_KC(X) OBGC_BGC_DIAG_KCA(X) OBGC_BGC_DIAG_CA(X) OBGC_BGC_DIAG_C(X)
+#undef X
+#define X(n) if (dg_dms.n) dg_dms.n += c0;
+  OBGC_DMS_DIAG_KC(X)
+#undef X
+#define X(n) if (dg_macros.n) dg_macros.n += c0;
+  OBGC_MACROS_DIAG_KC(X)
+#undef X
   obgc_bgc_source_sink_args ss;
   std::memset(&ss, 0, sizeof ss);
   ss.grid = g; ss.tracers = b->tracers + c0; ss.temp = b->temp + c0; ss.salt = b->salt + c0; ss.zmid = b->zmid + c0;
   ss.dz = b->dz + c0; ss.zbot = b->zbot + c0;
   ss.lat = b->lat + c0; ss.kmax = m.kmax + c0; ss.fesedflux = b->fesed + c0; ss.dust_flux_in = b->dust + c0; ss.sw_flux = b->sw + c0;
-  ss.tend = b->tend + c0; ss.ph_prev = b->php + c0; ss.ph_prev_alt = b->pha + c0; ss.diag = nullptr; ss.alt_co2_use_eco = 0;
+  ss.tend = b->tend + c0; ss.ph_prev = b->php + c0; ss.ph_prev_alt = b->pha + c0; ss.diag = b->have_bgc_diag ? &dg_bgc : nullptr; ss.alt_co2_use_eco = 0;
   if (with_dms) {
     // DMS_SurfaceFluxes reads the surface row of ONE tracer (DMS_mod.F90:834): a one-level 14-plane array holds it
     const obgc_dms_params& dp = b->h->dms;
@@ -372,10 +408,12 @@ int block_step_range(obgc_block* b, const obgc_block_step_args* a, int c0, int c
     if (with_dms) {
       fs.dms = b->own + c0; fs.dmsp = b->own + plane + c0; fs.SST = b->sst + c0;
       fs.dms_tend = b->own_tend + c0; fs.dmsp_tend = b->own_tend + plane + c0;
+      if (b->have_dms_diag) fs.dms_diag = &dg_dms;
     }
     if (with_macros) {
       fs.prot = b->own + 2 * plane + c0; fs.poly = b->own + 3 * plane + c0; fs.lip = b->own + 4 * plane + c0;
       fs.prot_tend = b->own_tend + 2 * plane + c0; fs.poly_tend = b->own_tend + 3 * plane + c0; fs.lip_tend = b->own_tend + 4 * plane + c0;
+      if (b->have_macros_diag) fs.macros_diag = &dg_macros;
     }
     rc = obgc_fused_step(b->h, &fs);
   } else {
