@@ -420,6 +420,15 @@ typedef struct {
  * inside the block); with dmsTracers / macrosTracers also DMS_SurfaceFluxes and the fused BGC + DMS + MACROS step */
 int obgc_block_step(obgc_block *b, const obgc_block_step_args *a);
 
+/* The state a block carries between steps -- PH_PREV_3D, PH_PREV_ALT_CO2_3D (BGC_mod.F90:935-1001) and surface_pH,
+ * surface_pH_alt_co2 (BGC_mod.F90:2816-2900), which the reference keeps in the host's arrays -- for the model's restart
+ * file: HOST arrays in the model's order, (nVertLevels, nCells) level-fastest and (nCells), the arguments of
+ * obgc_restart_write / obgc_restart_read.  A fresh block starts from zeros (no previous pH: the wide first bracket).
+ * Both calls wait for the block's pending steps. */
+int obgc_block_get_state(obgc_block *b, double *ph_prev, double *ph_prev_alt, double *surface_pH, double *surface_pH_alt);
+int obgc_block_set_state(obgc_block *b, const double *ph_prev, const double *ph_prev_alt, const double *surface_pH,
+                         const double *surface_pH_alt);
+
 /* Diagnostics of the block's steps.  The block keeps its state in the native layout, so diagnostics are computed into
  * DEVICE arrays of that index space: COLFAST, nlev = nVertLevels, ncol = ld = ldc = nCells -- what an obgc_diag_set created
  * for such a grid owns (pass obgc_diag_set_bgc / _dms / _macros of the set; the host then accumulates, downloads or writes

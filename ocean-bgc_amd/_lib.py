@@ -209,6 +209,8 @@ PROTOTYPES = {
     "obgc_block_step": (C.c_int, [C.c_void_p, C.POINTER(BlockStepArgs)]),
     "obgc_block_step_device": (C.c_int, [C.c_void_p, C.POINTER(BlockStepArgs)]),
     "obgc_block_set_diagnostics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "obgc_block_get_state": (C.c_int, [C.c_void_p, _dptr, _dptr, _dptr, _dptr]),
+    "obgc_block_set_state": (C.c_int, [C.c_void_p, _dptr, _dptr, _dptr, _dptr]),
     "obgc_diag_set_rows": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "obgc_diag_set_create": (C.c_int, [C.c_void_p, C.POINTER(Grid), C.c_int, C.POINTER(C.c_char_p), _dptr, _dptr, C.POINTER(C.c_void_p)]),
     "obgc_diag_set_destroy": (C.c_int, [C.c_void_p]),

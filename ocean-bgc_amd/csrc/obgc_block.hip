@@ -226,6 +226,47 @@ extern "C" int obgc_block_destroy(obgc_block* b) {
   return OBGC_OK;
 }
 
+// The state a block carries from step to step (the reference keeps it in the host's BGC_output / BGC_forcing arrays,
+// BGC_mod.F90:935-1001, 2816-2900): previous pH of the interior and of the surface, both forms.  Host side in the model's
+// order, (nVertLevels, nCells) level-fastest; the block holds the two planes column-fastest.  Restart-time calls: the planes
+// go through one staging vector and a host transpose.
+extern "C" int obgc_block_get_state(obgc_block* b, double* ph_prev, double* ph_prev_alt, double* surface_pH, double* surface_pH_alt) {
+  if (!b || !ph_prev || !ph_prev_alt || !surface_pH || !surface_pH_alt) return OBGC_ERR_INVALID;
+  if (hipSetDevice(handle_device(b->h)) != hipSuccess) return OBGC_ERR_HIP;
+  if (obgc_sync(b->h) != OBGC_OK) return OBGC_ERR_HIP;
+  const size_t nc = (size_t)b->nc, nz = (size_t)b->nz, d = sizeof(double);
+  std::vector<double> tmp(nc * nz);
+  const double* src[2] = {b->php, b->pha};
+  double* dst[2] = {ph_prev, ph_prev_alt};
+  for (int i = 0; i < 2; ++i) {
+    if (hipMemcpy(tmp.data(), src[i], nc * nz * d, hipMemcpyDeviceToHost) != hipSuccess) return OBGC_ERR_HIP;
+    for (size_t c = 0; c < nc; ++c)
+      for (size_t k = 0; k < nz; ++k) dst[i][c * nz + k] = tmp[k * nc + c];
+  }
+  if (hipMemcpy(surface_pH, b->sph, nc * d, hipMemcpyDeviceToHost) != hipSuccess) return OBGC_ERR_HIP;
+  if (hipMemcpy(surface_pH_alt, b->spha, nc * d, hipMemcpyDeviceToHost) != hipSuccess) return OBGC_ERR_HIP;
+  return OBGC_OK;
+}
+
+extern "C" int obgc_block_set_state(obgc_block* b, const double* ph_prev, const double* ph_prev_alt, const double* surface_pH,
+                                    const double* surface_pH_alt) {
+  if (!b || !ph_prev || !ph_prev_alt || !surface_pH || !surface_pH_alt) return OBGC_ERR_INVALID;
+  if (hipSetDevice(handle_device(b->h)) != hipSuccess) return OBGC_ERR_HIP;
+  if (obgc_sync(b->h) != OBGC_OK) return OBGC_ERR_HIP;
+  const size_t nc = (size_t)b->nc, nz = (size_t)b->nz, d = sizeof(double);
+  std::vector<double> tmp(nc * nz);
+  const double* src[2] = {ph_prev, ph_prev_alt};
+  double* dst[2] = {b->php, b->pha};
+  for (int i = 0; i < 2; ++i) {
+    for (size_t c = 0; c < nc; ++c)
+      for (size_t k = 0; k < nz; ++k) tmp[k * nc + c] = src[i][c * nz + k];
+    if (hipMemcpy(dst[i], tmp.data(), nc * nz * d, hipMemcpyHostToDevice) != hipSuccess) return OBGC_ERR_HIP;
+  }
+  if (hipMemcpy(b->sph, surface_pH, nc * d, hipMemcpyHostToDevice) != hipSuccess) return OBGC_ERR_HIP;
+  if (hipMemcpy(b->spha, surface_pH_alt, nc * d, hipMemcpyHostToDevice) != hipSuccess) return OBGC_ERR_HIP;
+  return OBGC_OK;
+}
+
 extern "C" int obgc_block_set_diagnostics(obgc_block* b, const obgc_bgc_diag* bgc, const obgc_dms_diag* dms, const obgc_macros_diag* macros) {
   if (!b) return OBGC_ERR_INVALID;
   std::memset(&b->bgc_diag, 0, sizeof b->bgc_diag);

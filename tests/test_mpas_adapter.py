@@ -229,6 +229,11 @@ def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, 
     run(EXE_GPU, fin, fout, 0, nsteps)
     host = read_result(fout, nc, nz)
     assert np.array_equal(tend, host["tend"]) and np.array_equal(sflux, host["sflux"])
+    # the state the block carries = the arrays the host adapter keeps, in the model's order
+    st = [np.full((nc, nz), -1.0), np.full((nc, nz), -1.0), np.full(nc, -1.0), np.full(nc, -1.0)]
+    assert E.lib.obgc_block_get_state(blk, *[x.ctypes.data_as(C.c_void_p) for x in st]) == 0
+    for got, key in zip(st, ("php", "pha", "sph", "spha")):
+        assert np.array_equal(got, host[key]), key
     want = expected(oracle, pk, m, nc, nz, nsteps)
     rep = P.Report()
     P.compare_tend(rep, "block.tend", tend.transpose(2, 0, 1), want["tend"].transpose(2, 0, 1))
@@ -245,7 +250,26 @@ def test_resident_block_equals_host_adapter_and_matches_oracle(tmp_path, synth, 
         block_step(L, E, blk2, m, nc, nz, over, accumulate=False)
     active = (np.arange(nz)[None, :] < m["kmax"][:, None])[:, :, None]
     assert np.array_equal(acc, np.where(active, base + over, base))
-    assert E.lib.obgc_block_destroy(blk) == 0 and E.lib.obgc_block_destroy(blk2) == 0
+    # restart: a fresh block given the state of two steps takes the third step of the uninterrupted block
+    blk3 = C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk3)) == 0
+    assert E.lib.obgc_block_set_state(blk3, *[x.ctypes.data_as(C.c_void_p) for x in st]) == 0
+    resumed = np.zeros((nc, nz, 30))
+    sflux3 = block_step(L, E, blk3, m, nc, nz, resumed, accumulate=False)
+    assert np.array_equal(resumed, over) and np.abs(sflux3).max() > 0
+    # ... and ends in the state of the uninterrupted one (the warm brackets were the same), which a cold block does not
+    def state_of(b):
+        x = [np.empty((nc, nz)), np.empty((nc, nz)), np.empty(nc), np.empty(nc)]
+        assert E.lib.obgc_block_get_state(b, *[y.ctypes.data_as(C.c_void_p) for y in x]) == 0
+        return x
+    for a3, a2 in zip(state_of(blk3), state_of(blk2)):
+        assert np.array_equal(a3, a2)
+    blk4 = C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk4)) == 0
+    block_step(L, E, blk4, m, nc, nz, np.zeros((nc, nz, 30)), accumulate=False)
+    assert not np.array_equal(state_of(blk4)[0], state_of(blk2)[0])
+    for b in (blk, blk2, blk3, blk4):
+        assert E.lib.obgc_block_destroy(b) == 0
 
 
 @pytest.mark.gpu
