@@ -22,7 +22,8 @@ struct obgc_block {
   double *depo, *river, *gas, *seaice, *net;
   int* kmax;
   // staging of the model's arrays (model layout)
-  double *m_tr = nullptr, *m_h, *m_zmid, *m_t, *m_s, *m_fesed, *m_tend, *m_sflux, *m_c[8];
+  double *m_tr = nullptr, *m_h = nullptr, *m_zmid = nullptr, *m_t = nullptr, *m_s = nullptr, *m_fesed = nullptr, *m_tend = nullptr,
+         *m_sflux = nullptr, *m_c[8] = {};
   // pipelined step: cell chunks, results of chunk i go down on s_down while chunk i+1 comes up on the engine's stream
   enum { kMaxChunks = 16 };
   int chunks = 8, min_cells = 8192, threads = 1;   // OBGC_HOST_THREADS=0: downloads in line
@@ -235,7 +236,8 @@ extern "C" int obgc_block_get_state(obgc_block* b, double* ph_prev, double* ph_p
   if (hipSetDevice(handle_device(b->h)) != hipSuccess) return OBGC_ERR_HIP;
   if (obgc_sync(b->h) != OBGC_OK) return OBGC_ERR_HIP;
   const size_t nc = (size_t)b->nc, nz = (size_t)b->nz, d = sizeof(double);
-  std::vector<double> tmp(nc * nz);
+  std::vector<double> tmp;
+  try { tmp.resize(nc * nz); } catch (...) { return OBGC_ERR_ALLOC; }
   const double* src[2] = {b->php, b->pha};
   double* dst[2] = {ph_prev, ph_prev_alt};
   for (int i = 0; i < 2; ++i) {
@@ -254,7 +256,8 @@ extern "C" int obgc_block_set_state(obgc_block* b, const double* ph_prev, const 
   if (hipSetDevice(handle_device(b->h)) != hipSuccess) return OBGC_ERR_HIP;
   if (obgc_sync(b->h) != OBGC_OK) return OBGC_ERR_HIP;
   const size_t nc = (size_t)b->nc, nz = (size_t)b->nz, d = sizeof(double);
-  std::vector<double> tmp(nc * nz);
+  std::vector<double> tmp;
+  try { tmp.resize(nc * nz); } catch (...) { return OBGC_ERR_ALLOC; }
   const double* src[2] = {ph_prev, ph_prev_alt};
   double* dst[2] = {b->php, b->pha};
   for (int i = 0; i < 2; ++i) {
