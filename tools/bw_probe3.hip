@@ -59,6 +59,87 @@ __global__ __launch_bounds__(256, 2) void probe_pairs(const double2* __restrict_
   }
 }
 
+// the same march with every workgroup starting its plane loops at a different plane (a rotation by a hash of the block
+// index): whether workgroups that move through the planes in lock-step camp on the same channels
+template <int NIN, int NOUT>
+__global__ __launch_bounds__(256, 2) void probe_rot(const double* __restrict__ in, double* __restrict__ out, int nlev, long long nblk) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const unsigned h = (unsigned)b * 2654435761u;
+  const int r_in = NIN ? (int)((h >> 8) % (unsigned)(NIN ? NIN : 1)) : 0, r_out = (int)((h >> 12) % (unsigned)NOUT);
+  for (int k = w; k < nlev; k += 4) {
+    double acc = 0.0;
+    for (int q = 0; q < NIN; ++q) { int p = q + r_in; if (p >= NIN) p -= NIN; acc += in[addr<2>(p, k, b, lane, NIN, nlev, nblk)]; }
+    if (acc == 12345.678) lds[threadIdx.x] = acc;
+    for (int q = 0; q < NOUT; ++q) { int p = q + r_out; if (p >= NOUT) p -= NOUT; out[addr<2>(p, k, b, lane, NOUT, nlev, nblk)] = acc + p; }
+  }
+}
+
+// the same march with the NEXT level's loads requested before the current level's stores are issued (their values wait in
+// registers until the stores are out): what the load -> wait -> store order of a level costs
+template <int NIN, int NOUT>
+__global__ __launch_bounds__(256, 2) void probe_ahead(const double* __restrict__ in, double* __restrict__ out, int nlev, long long nblk) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  double v[NIN];
+  if (w < nlev) {
+#pragma unroll
+    for (int p = 0; p < NIN; ++p) v[p] = in[addr<2>(p, w, b, lane, NIN, nlev, nblk)];
+  }
+  for (int k = w; k < nlev; k += 4) {
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < NIN; ++p) acc += v[p];
+    if (acc == 12345.678) lds[threadIdx.x] = acc;
+    if (k + 4 < nlev) {
+#pragma unroll
+      for (int p = 0; p < NIN; ++p) v[p] = in[addr<2>(p, k + 4, b, lane, NIN, nlev, nblk)];
+    }
+#pragma unroll
+    for (int p = 0; p < NOUT; ++p) out[addr<2>(p, k, b, lane, NOUT, nlev, nblk)] = acc + p;
+#pragma unroll
+    for (int p = 0; p < NIN; ++p) asm volatile("" : "+v"(v[p]));   // the loaded values are not touched before the stores are out
+  }
+}
+
+template <int NIN, int NOUT>
+void run_ahead(const double* in, double* out, int ncol, int nlev) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const long long nblk = ncol / 64;
+  const size_t shm = g_shm_kb * 1024;
+  CK(hipFuncSetAttribute((const void*)probe_ahead<NIN, NOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int r = 0; r < 2; ++r) probe_ahead<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
+  CK(hipEventRecord(a));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) probe_ahead<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+  const double bytes = 8.0 * nblk * 64 * nlev * (NIN + NOUT);
+  printf("in %3d out %3d, column blocks, next level's loads ahead of the stores  : %8.3f ms  %6.2f TB/s\n", NIN, NOUT, ms, bytes / ms * 1e-9);
+  fflush(stdout);
+}
+
+template <int NIN, int NOUT>
+void run_rot(const double* in, double* out, int ncol, int nlev) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const long long nblk = ncol / 64;
+  const size_t shm = g_shm_kb * 1024;
+  CK(hipFuncSetAttribute((const void*)probe_rot<NIN, NOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int r = 0; r < 2; ++r) probe_rot<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
+  CK(hipEventRecord(a));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) probe_rot<NIN, NOUT><<<(unsigned)nblk, 256, shm>>>(in, out, nlev, nblk);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+  const double bytes = 8.0 * nblk * 64 * nlev * (NIN + NOUT);
+  printf("in %3d out %3d, column blocks, plane order rotated per workgroup      : %8.3f ms  %6.2f TB/s\n", NIN, NOUT, ms, bytes / ms * 1e-9);
+  fflush(stdout);
+}
+
 template <int NIN, int NOUT>
 void run_pairs(const double* in, double* out, int ncol, int nlev) {
   hipEvent_t a, b;
@@ -112,6 +193,9 @@ int main(int argc, char** argv) {
   run<43, 200, 0, 0, 4>(in, out, ncol, nlev);
   run<43, 200, 0, 2, 4>(in, out, ncol, nlev);
   run<43, 200, 2, 2, 4>(in, out, ncol, nlev);
+  run_ahead<43, 200>(in, out, ncol, nlev);
+  run_rot<43, 200>(in, out, ncol, nlev);
+  run_rot<0, 200>(in, out, ncol, nlev);
   run_pairs<44, 200>(in, out, ncol, nlev);
   run_pairs<0, 200>(in, out, ncol, nlev);
   run<43, 37, 0, 0, 0>(in, out, ncol, nlev);    // tendencies only
