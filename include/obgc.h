@@ -444,7 +444,8 @@ int obgc_block_set_diagnostics(obgc_block *b, const obgc_bgc_diag *bgc, const ob
  * are not modified apart from the outputs (the package's in-place Fe scaling of the flux arrays works on copies).
  * Same kernels and arithmetic as obgc_block_step: same bits.  Runs on the handle's stream; returns after enqueue on a
  * handle created with OBGC_ASYNC (obgc_sync completes it), after completion otherwise.  The two forms may be mixed on
- * one block. */
+ * one block.  Host arrays are refused with OBGC_ERR_INVALID (the tracer and tendency arrays are looked up with
+ * hipPointerGetAttributes) instead of being handed to a kernel. */
 int obgc_block_step_device(obgc_block *b, const obgc_block_step_args *a);
 
 /* --------------------------------------- diagnostics kept on the device

@@ -599,9 +599,26 @@ extern "C" int obgc_block_step(obgc_block* b, const obgc_block_step_args* a) {
 
 // The same step for a model whose arrays already live on this GPU: the pack kernels read the caller's arrays, the unpack
 // kernels write (or add to) the caller's tendency and flux arrays; nothing is staged and nothing crosses the link.
+namespace {
+
+// a pointer the kernels may dereference: device or managed memory (a host pointer handed to this entry point would fault)
+bool on_device(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();   // plain host memory is reported as an error: clear it
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+}  // namespace
+
 extern "C" int obgc_block_step_device(obgc_block* b, const obgc_block_step_args* a) {
   if (!b || !a) return OBGC_ERR_INVALID;
   if (!block_args_complete(a)) return OBGC_ERR_INVALID;
+  // (one input and one output are looked up, 1-2 us each; looking up all 25 would show in the step of a small block)
+  if (!on_device(a->ecosysTracers) || !on_device(a->ecosysTracersTend))
+    return fail(b->h, OBGC_ERR_INVALID, "obgc_block_step_device: the arrays must be device memory (host arrays go to obgc_block_step)");
   const int nc = b->nc;
   const size_t d = sizeof(double);
   if (hipSetDevice(handle_device(b->h)) != hipSuccess) return OBGC_ERR_HIP;

@@ -422,6 +422,10 @@ def test_resident_block_device_pointers_same_bits_as_host_pointers(synth, pkg, m
         assert np.abs(th).max() > 0 and not np.array_equal(th, np.full_like(th, fill))
         if with_own:
             assert np.array_equal(dh, dd) and np.array_equal(mh, md) and np.array_equal(dsf_h, dsf_d)
+    # host arrays handed to the device entry point: an error code and a message, no kernel is launched on them
+    a, keep, _ = block_args(L, m, nc, nz, np.zeros((nc, nz, 30)), False)
+    assert E.lib.obgc_block_step_device(blk_d, C.byref(a)) != 0
+    assert b"must be device memory" in E.lib.obgc_last_error(E.h)
     assert E.lib.obgc_block_destroy(blk_h) == 0 and E.lib.obgc_block_destroy(blk_d) == 0
 
 
