@@ -1,7 +1,7 @@
 # A wider net than the test-suite casts: GPU vs oracle over many blocks of synthetic columns (cold call, then a warm call on
 # perturbed tracers with the previous pH), 60, 80 and 100 levels, worst case per class.  The cold call is the fused
 # BGC + DMS + MACROS step (the headline path), the warm call BGC_SourceSink alone.  ~2 minutes for 8 blocks, mostly oracle time.
-# python tools/parity_soak.py [blocks [path]]      (on an MI355X; the oracle only checks here; path = device_colfast (default:
+# python tools/parity_soak.py [blocks [path [columns per block]]]   (on an MI355X; the oracle only checks here; path = device_colfast (default:
 # blocks below 700 000 cells then run on the separate kernels, OBGC_COLUMN_KERNEL=2 forces the column-block kernel) or device_tiled)
 import os, sys
 import numpy as np
@@ -14,11 +14,13 @@ from ocean_bgc_amd import synth
 from ocean_bgc_amd.modules import ColumnEngine
 from oracle import orabind
 nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+# (blocks of at most 3 000 columns stay under 300 000 cells: the native layout then runs the sweep as recurrence-only walk + cell-parallel kernels)
+NCOLS = int(sys.argv[3]) if len(sys.argv) > 3 else 8000
 E, O = ColumnEngine(0, path=sys.argv[2] if len(sys.argv) > 2 else "device_colfast"), orabind.Oracle()
 worst, bad = {}, 0
 for b in range(nblocks):
     nz = (60, 80, 100)[b % 3]
-    nc, col0 = 8000, 1_000_003 * b + 17
+    nc, col0 = NCOLS, 1_000_003 * b + 17
     syn = synth.generate(nc, nz, col0=col0)
     tr = synth.bgc_tracer_array(syn)
     rest = (syn["temp"], syn["salt"], syn["zmid"], syn["dz"], syn["zbot"], syn["lat"], syn["kmax"], syn["fesed"], syn["dust"], syn["sw"])
