@@ -507,3 +507,50 @@ def test_resident_block_fills_a_diagnostic_set(synth, pkg, monkeypatch, chunks):
     assert np.array_equal(ds.download("CO3", "inst"), before)
     ds.close()
     assert E.lib.obgc_block_destroy(blk) == 0 and E.lib.obgc_block_destroy(plain) == 0
+
+
+@pytest.mark.gpu
+def test_fortran_resident_block_with_diagnostics_and_state(tmp_path, synth, pkg):
+    """The Fortran module obgc_mpas_resident with obgc_mpas_resident_select_diagnostics / _accumulate / _get_diagnostic /
+    _get_state (test program mode 3): the means of the selected members over the steps and the carried pH state are the bits
+    the Python host gets from the same block through the C ABI."""
+    import ctypes as C
+    if not has_gpu():
+        pytest.fail("needs a GPU")
+    if not os.path.exists(EXE_GPU):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    from ocean_bgc_amd import _lib as L
+    from ocean_bgc_amd.engine import Engine
+    nc, nz, nsteps = 640, 60, 3
+    m, pk = mpas_block(synth, nc, nz, col0=120000)
+    fin, fout = str(tmp_path / "blk.bin"), str(tmp_path / "out3.bin")
+    write_block(fin, m, nc, nz)
+    run(EXE_GPU, fin, fout, 3, nsteps)
+    raw = np.fromfile(fout, dtype=np.float64)
+    got, pos = {}, 0
+    for nm, shape in (("tend", (nc, nz, 30)), ("sflux", (nc, 30)), ("x0", (nc, nz)), ("x1", (nc, nz)), ("x2", (nc,)), ("x3", (nc,)),
+                      ("co3", (nc, nz)), ("pcz", (nc,)), ("php", (nc, nz)), ("pha", (nc, nz)), ("sph", (nc,)), ("spha", (nc,))):
+        n = int(np.prod(shape))
+        got[nm] = raw[pos:pos + n].reshape(shape)
+        pos += n
+    assert pos == raw.size
+    E = Engine(0)
+    blk = C.c_void_p()
+    assert E.lib.obgc_block_create(E.h, nc, nz, C.byref(blk)) == 0
+    ds = E.diag_set(nz, nc, ["CO3", "photoC_TOT_zint", "dms.DMS_R_TOTAL"])
+    void = lambda p: C.cast(p, C.c_void_p) if p else None
+    assert E.lib.obgc_block_set_diagnostics(blk, void(ds.bgc), void(ds.dms), void(ds.macros)) == 0
+    tend = np.zeros((nc, nz, 30))
+    for s in range(nsteps):
+        tend[:] = 0.0
+        sflux = block_step(L, E, blk, m, nc, nz, tend, accumulate=True)      # the Fortran program accumulates into zeros
+        ds.accumulate(1.0 / nsteps, reset=(s == 0))
+    st = [np.empty((nc, nz)), np.empty((nc, nz)), np.empty(nc), np.empty(nc)]
+    assert E.lib.obgc_block_get_state(blk, *[x.ctypes.data_as(C.c_void_p) for x in st]) == 0
+    assert np.array_equal(got["tend"], tend) and np.array_equal(got["sflux"], sflux)
+    assert np.array_equal(got["co3"], ds.download("CO3")) and np.array_equal(got["pcz"], ds.download("photoC_TOT_zint"))
+    for key, ref in zip(("php", "pha", "sph", "spha"), st):
+        assert np.array_equal(got[key], ref), key
+    assert (got["co3"] > 0).any() and np.isfinite(got["co3"]).all()
+    ds.close()
+    assert E.lib.obgc_block_destroy(blk) == 0
